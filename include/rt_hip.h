@@ -1,0 +1,216 @@
+/* rt_hip.h -- C ABI of the MI355X-native trace loop (libraytracer_hip.so).
+ *
+ * This is the drop-in boundary for the per-pixel trace loop of cosmcif/raytracer (reference main.cpp:607-650
+ * and everything it calls: trace_ray :221, closest :59, is_shadowed :41, PhongModel :81, toneMapping :240,
+ * Sphere/Plane::intersect Objects.h:38,138, Triangle/BoundingBox/MeshLoader::intersect MeshLoader.h:70,151,392,
+ * the texture functions Textures.h:12-188, Image::setPixel Image.h:91-95).
+ *
+ * The reference has no FFI of its own: its seam is source-level -- three mutable globals
+ * `lights`, `ambient_light`, `objects` (main.cpp:36-38) read by trace_ray().  Each entry point below names the
+ * reference construct it stands in for.  Plain C types only; every pointer is a HOST pointer unless the name
+ * starts with d_ (device pointer, e.g. torch.Tensor.data_ptr()).  Input buffers are copied during the call; the
+ * library owns all device memory until rt_destroy().  Every function returns 0 on success, non-zero on
+ * failure; rt_last_error() then describes the failure (thread-local).  A context is bound to one GPU and is not
+ * re-entrant.  There is no CPU fallback: without a usable HIP device rt_create() fails.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+/* Material function pointers of the reference (Material.h:26,30,40,41) become IDs. */
+enum rt_texture_id {
+    RT_TEX_NONE = 0,
+    RT_TEX_PERLIN_NORMAL = 1,      /* Textures.h:22  */
+    RT_TEX_PERLIN_WATER = 2,       /* Textures.h:39  */
+    RT_TEX_OPAL = 3,               /* Textures.h:55  */
+    RT_TEX_PERLIN_TERRAIN = 4,     /* Textures.h:76  */
+    RT_TEX_PERLIN_ICE_TERRAIN = 5, /* Textures.h:87  */
+    RT_TEX_SNOW_TERRAIN = 6,       /* Textures.h:102 */
+    RT_TEX_QWILFISH = 7,           /* Textures.h:123 */
+    RT_TEX_BMP_COLOR = 8,          /* Textures.h:173 colorAt            (BMP slot 0) */
+    RT_TEX_BMP_NORMAL = 9,         /* Textures.h:178 normalAt           (BMP slot 1) */
+    RT_TEX_BMP_ROUGHNESS = 10,     /* Textures.h:186 roughnessAt        (BMP slot 2) */
+    RT_TEX_BMP_OCCLUSION = 11,     /* Textures.h:182 ambientOcclusionAt (BMP slot 3) */
+    RT_TEX_COUNT = 12
+};
+
+/* struct Material, reference Material.h:14-42 (same fields, same defaults expected from the caller). 96 bytes. */
+typedef struct rt_material {
+    float ambient[3];
+    float diffuse[3];
+    float specular[3];
+    float reflection;
+    float refraction;
+    float sigma;
+    float shininess;
+    int32_t texture;         /* rt_texture_id, 0 = nullptr */
+    int32_t has_normal_map;  /* bool hasNormalMap */
+    int32_t normal_map;      /* rt_texture_id */
+    int32_t is_anisotropic;
+    float alpha_x;
+    float alpha_y;
+    int32_t has_img_texture;
+    int32_t roughness;       /* rt_texture_id */
+    int32_t occlusion;       /* rt_texture_id */
+    int32_t _pad[2];
+} rt_material;
+
+/* Camera of the tile loop, reference main.cpp:561-563,570-578,629-641.  rot is column-major (glm layout) and is
+ * always applied (identity for sampleScene); dz is +1 (sampleScene, main.cpp:634) or -1 (competitionScene, :637). */
+typedef struct rt_camera {
+    float origin[3];
+    float dz;
+    float rot[16];
+    float fov_deg;
+    float _pad[3];
+} rt_camera;
+
+enum rt_jitter_mode {
+    RT_JITTER_AUTO = 0,  /* reference table when spp == 4, counter-based hash otherwise */
+    RT_JITTER_TABLE = 1, /* reference jitterMatrix, main.cpp:601-606; requires spp == 4 */
+    RT_JITTER_HASH = 2   /* rt_hash32-based jitter in [-0.75, 0.75) px, see DESIGN.md */
+};
+
+typedef struct rt_render_params {
+    int32_t width;
+    int32_t height;
+    int32_t spp;            /* samples per pixel, reference: 4 (main.cpp:625) */
+    int32_t max_depth;      /* bounce depth, reference: 3 (main.cpp:643) */
+    uint32_t seed;          /* hash-jitter seed */
+    int32_t jitter_mode;    /* rt_jitter_mode */
+    int32_t tile_rank;      /* this context renders tiles t with t % tile_world == tile_rank (16x16 tiles, main.cpp:565) */
+    int32_t tile_world;     /* 1 = whole image */
+    int64_t chunk_samples;  /* primary samples per wavefront chunk; 0 = default */
+    int32_t collect_stats;  /* 1 = count BVH nodes / triangle tests in-kernel (slower) */
+    int32_t _pad;
+} rt_render_params;
+
+typedef struct rt_stats {
+    uint64_t primary_samples;
+    uint64_t rays_closest;    /* primary + reflection + refraction rays traced (Ray ctor at main.cpp:156,183,642) */
+    uint64_t rays_shadow;     /* shadow rays traced (Ray ctor at main.cpp:49; back-face culled ones are not rays) */
+    uint64_t shadow_culled;   /* lights rejected by main.cpp:44-46 */
+    uint64_t hits_shaded;     /* PhongModel invocations */
+    uint64_t nodes_visited;   /* BVH nodes fetched   (collect_stats only) */
+    uint64_t tris_tested;     /* triangle tests      (collect_stats only) */
+    uint64_t queue_overflow;  /* must be 0 */
+    double ms_total;          /* GPU time of the whole call (HIP events) */
+    double ms_gen, ms_closest, ms_shade, ms_any, ms_resolve; /* per kernel class, summed over launches */
+    uint64_t launches_closest, launches_any;
+    uint64_t bvh_nodes, bvh_depth, n_triangles;
+} rt_stats;
+
+/* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */
+typedef struct rt_hit {
+    int32_t hit;
+    int32_t object;      /* index into the scene's object list, -1 on miss */
+    int32_t triangle;    /* triangle index inside its mesh, -1 for sphere / plane / miss */
+    uint32_t prim;       /* global primitive id (rt_render's out_primid encoding) */
+    float distance;
+    float intersection[3];
+    float normal[3];
+    float normal_shading[3];
+    float uv[2];
+    float tangent[3];
+    float bitangent[3];
+    float _pad[2];
+} rt_hit;
+
+#define RT_PRIM_MISS 0xFFFFFFFFu
+#define RT_PRIM_ANALYTIC 0x80000000u /* | object index, for spheres and planes; triangles use their global index */
+
+const char *rt_last_error(void);
+
+/* Device bring-up. Fails (no fallback) when device_id is not a usable HIP device. */
+int rt_create(int device_id, rt_context **out);
+int rt_destroy(rt_context *ctx);
+
+/* -- scene upload: stands in for filling the globals `objects`, `lights`, `ambient_light` (main.cpp:36-38) -- */
+
+/* Material table. Objects refer to it through rt_set_object_materials(). */
+int rt_set_materials(rt_context *ctx, int32_t n, const rt_material *materials);
+
+/* object_material[o] = material index of scene object o (mesh, sphere or plane), in `objects` order.
+ * Object order decides exact distance ties (first object wins, main.cpp:67). */
+int rt_set_object_materials(rt_context *ctx, int32_t n_objects, const int32_t *object_material);
+
+/* All mesh triangles of the scene, grouped by object in `objects` order and in file order inside a mesh, i.e.
+ * what MeshLoader (MeshLoader.h:300-390) leaves in `triangles`, translation already baked in.
+ * v0,v1,v2,nA,nB,nC: n*3 floats; tA,tB,tC: n*2 floats; flags bit0 = vertexNormals, bit1 = vertexTextures
+ * (Triangle ctor, MeshLoader.h:62-68); object_id[n] non-decreasing. */
+int rt_set_triangles(rt_context *ctx, int64_t n, const float *v0, const float *v1, const float *v2,
+                     const float *nA, const float *nB, const float *nC, const float *tA, const float *tB,
+                     const float *tC, const uint32_t *flags, const int32_t *object_id);
+
+/* Spheres (Objects.h:12-104): unit sphere under a transformation; the three matrices are what
+ * Object::setTransformation (Object.h:53-57) stores, column-major, n*16 floats each. */
+int rt_set_spheres(rt_context *ctx, int32_t n, const float *M, const float *Minv, const float *Nmat,
+                   const int32_t *object_id);
+
+/* Planes (Objects.h:109-183): point[n*3], normal[n*3]. */
+int rt_set_planes(rt_context *ctx, int32_t n, const float *point, const float *normal, const int32_t *object_id);
+
+/* Point lights (main.cpp:26-34) and ambient_light (main.cpp:37). */
+int rt_set_lights(rt_context *ctx, int32_t n, const float *position, const float *color, const float *ambient);
+
+/* One of the four BMP maps of Textures.h:168-171, already decoded as bmpmini.hpp:65-88 leaves it:
+ * top-down rows, BGR byte order, `channels` bytes per pixel.  slot: 0 color, 1 normal, 2 roughness, 3 occlusion. */
+int rt_set_bmp(rt_context *ctx, int32_t slot, int32_t width, int32_t height, int32_t channels,
+               const uint8_t *bytes);
+
+/* Flatten check, BVH build (linear 32-byte nodes), upload.  Must precede rendering; may be repeated. */
+int rt_commit(rt_context *ctx);
+
+/* -- the render loop: stands in for main.cpp:607-650 (+ toneMapping :240, Image::setPixel Image.h:91-95) -- */
+
+/* Whole-image render into host buffers (any may be NULL): out_rgb8[h*w*3] row-major as Image::data but bytes,
+ * out_rgbf[h*w*3] = mean of the clamped samples before tone mapping (pixelColor/spp, main.cpp:646),
+ * out_primid[h*w] = primitive hit by sample 0 of the pixel.  Requires tile_world == 1. */
+int rt_render(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8,
+              float *out_rgbf, uint32_t *out_primid, rt_stats *stats);
+
+/* Number of 16x16 tiles of a w*h image that belong to `rank` of `world`, and the total. */
+int rt_tile_counts(int32_t width, int32_t height, int32_t rank, int32_t world, int64_t *n_local, int64_t *n_total);
+
+/* Multi-GPU form: renders only this rank's interleaved tiles into DEVICE buffers in tile-major order
+ * (local tile k = global tile k*world+rank; 256 pixels per tile, pixel (x,y) of the tile at y*16+x):
+ * d_rgb8[n_local*256*3] u8, d_rgbf[n_local*256*3] f32, d_primid[n_local*256] u32 (any may be NULL).
+ * Work is enqueued on `stream` (a hipStream_t, 0 = default) and is complete when the call returns. */
+int rt_render_tiles_device(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8,
+                           void *d_rgbf, void *d_primid, void *stream, rt_stats *stats);
+
+/* Assembles the image on the gathering rank: d_tiles_* hold the ranks' tile-major buffers back to back in rank
+ * order (exactly what an RCCL gather of rt_render_tiles_device outputs yields, ranks padded to `tiles_per_rank`
+ * tiles each); outputs are row-major device images.  No counterpart in the reference (single process). */
+int rt_assemble_tiles_device(rt_context *ctx, int32_t width, int32_t height, int32_t world,
+                             int64_t tiles_per_rank, const void *d_tiles_rgb8, const void *d_tiles_rgbf,
+                             const void *d_tiles_primid, void *d_rgb8, void *d_rgbf, void *d_primid, void *stream);
+
+/* -- trace_ray-style API (main.cpp:221-233) for batches of arbitrary rays; used by the parity tests -- */
+
+/* rays[n*6] = origin xyz, direction xyz (direction is used as given, as trace_ray does).
+ * out_color[n*3] = trace_ray(ray, depth) (clamped to [0,1]); out_hits[n] = closest(ray) (either may be NULL);
+ * out_shadow[n*4] = is_shadowed() per light for the closest hit as PhongModel calls it (1 = shadowed). */
+int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, float *out_color,
+                   rt_hit *out_hits, uint8_t *out_shadow, rt_stats *stats);
+
+/* Known-answer hooks for the texture functions: out[n*3] = texture_id(uv[n*2]) (scalar maps replicate .r);
+ * rt_eval_perlin: out[n] = glm::perlin(vec3 p[n*3]) (glm/gtc/noise.inl:65-132). */
+int rt_eval_texture(rt_context *ctx, int32_t texture_id, int64_t n, const float *uv, float *out);
+int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out);
+
+/* Read back the committed BVH (for the oracle-side counter checks): nodes[n_nodes*8] floats as stored,
+ * tri_order[n_triangles] = global triangle index held by BVH slot i.  Pass NULL to query sizes only. */
+int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE (oracle/_ref/ref_harness_O2, IEEE build; plus the
+-Ofast build for the noise-floor images).  Runs only in the authoring container (needs
+/root/reference to have been compiled by `make -C oracle ref`); the fixtures it writes are data -- seeded inputs
+and the reference's outputs -- and are committed.  Usage: python oracle/make_golden.py [--only NAME]
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, REPO)
+from raytracer_amd import _native as N  # noqa: E402
+from raytracer_amd.scene import FlatScene  # noqa: E402
+
+ASSETS = os.path.join(REPO, "assets")
+GOLD = os.path.join(REPO, "tests", "golden")
+O2 = os.path.join(HERE, "_ref", "ref_harness_O2")
+OFAST = os.path.join(HERE, "_ref", "ref_harness_Ofast")
+
+MESHES = [  # (file, translation) as placed by the shipped scenes
+    ("bunny.obj", (0, -3, 9)), ("piattaforma.obj", (0.3, -1.5, 0)), ("kyurem_ice_uv.obj", (-0.5, -0.425, 1.1)),
+    ("kyurem_body_uv.obj", (-0.5, -0.425, 1.1)), ("crystal_small_uv.obj", (-0.29, -0.39, 0.81)),
+    ("crystal_big_uv.obj", (-0.34, -0.388, 0.77)), ("qwilfish_body.obj", (-1.5, -0.65, 1.1)),
+    ("qwilfish_eyes.obj", (-1.5, -0.65, 1.1)), ("qwilfish_mouth.obj", (-1.5, -0.65, 1.1)),
+    ("crystalpillar.obj", (-0.565, -0.225, 1.46)),
+]
+
+
+def run(exe, *args):
+    out = subprocess.run([exe, *map(str, args)], cwd=ASSETS, check=True, capture_output=True, text=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else {}
+
+
+def ids_to_prim(ids, scene):
+    first = scene.mesh_first_triangle()
+    base = np.zeros(scene.n_objects + 1, np.int64)
+    for o, f in first.items():
+        base[o] = f
+    obj, tri = ids[..., 0].astype(np.int64), ids[..., 1].astype(np.int64)
+    prim = np.where(tri >= 0, base[np.clip(obj, 0, None)] + tri, N.PRIM_ANALYTIC | np.clip(obj, 0, None))
+    prim = np.where(obj < 0, N.PRIM_MISS, prim)
+    return prim.astype(np.uint32)
+
+
+def gen_perlin(tmp):
+    rng = np.random.default_rng(1)
+    pts = np.concatenate([
+        rng.uniform(-300, 300, (2048, 3)), rng.uniform(-4, 4, (1024, 3)),
+        rng.integers(-300, 300, (512, 3)).astype(np.float64),  # lattice points
+        np.array([[0, 0, 0], [-0.0, -0.0, 50.0], [288.5, 289.0, 289.5], [-289.0, 0.25, 1e-7]]),
+        rng.uniform(-1, 1, (508, 3)) * np.array([50.0, 50.0, 0.0]) + np.array([0, 0, 50.0]),
+    ]).astype(np.float32)
+    pin, pout = os.path.join(tmp, "p.in"), os.path.join(tmp, "p.out")
+    pts.tofile(pin)
+    run(O2, "perlin", pin, pout)
+    np.savez_compressed(os.path.join(GOLD, "perlin.npz"), points=pts, value=np.fromfile(pout, np.float32))
+
+
+def gen_textures(tmp):
+    rng = np.random.default_rng(2)
+    g = np.stack(np.meshgrid(np.linspace(0, 1, 24), np.linspace(0, 1, 24)), -1).reshape(-1, 2)
+    uv = np.concatenate([g, rng.uniform(0, 1, (448, 2)), rng.uniform(-8, 8, (512, 2)),
+                         rng.uniform(-1.2, -0.8, (64, 2)) * np.array([1.0, 1.0])]).astype(np.float32)
+    # BMP fetches are only defined for uv in [0,1) with fmod(v,1) != 0: keep a mask
+    uin, uout = os.path.join(tmp, "u.in"), os.path.join(tmp, "u.out")
+    bmp_ok = (uv >= 0).all(1) & (uv < 1).all(1) & (np.fmod(uv[:, 1], 1) != 0)
+    safe = uv.copy()
+    safe[~bmp_ok] = 0.5
+    uv.tofile(uin)
+    run(O2, "textures", uin, uout, 7)
+    proc = np.fromfile(uout, np.float32).reshape(11, len(uv), 3)
+    safe.tofile(uin)
+    run(O2, "textures", uin, uout)
+    bmp = np.fromfile(uout, np.float32).reshape(11, len(uv), 3)
+    names = ["perlinNormal", "perlinWater", "opal", "perlinTerrain", "perlinIceTerrain", "snowTerrain",
+             "qwilfishTexture", "colorAt", "normalAt", "roughnessAt", "ambientOcclusionAt"]
+    out = {"uv": uv, "uv_bmp": safe}
+    for k, n in enumerate(names):
+        out[n] = proc[k] if k < 7 else bmp[k]
+    np.savez_compressed(os.path.join(GOLD, "textures.npz"), **out)
+
+
+def gen_meshes(tmp):
+    meta, keep = {}, {}
+    for f, t in MESHES:
+        o = os.path.join(tmp, "m.out")
+        info = run(O2, "mesh", "./meshes/" + f, *t, o)
+        raw = np.fromfile(o, np.float32)
+        tri = raw[:-6].reshape(-1, 29)
+        meta[f] = dict(info, translation=list(t), sha256=hashlib.sha256(tri.tobytes()).hexdigest(),
+                       box=[float(x) for x in raw[-6:]], flat=int((tri[:, 27] == 0).sum()))
+        if f in ("bunny.obj", "qwilfish_eyes.obj"):
+            keep[f.replace(".", "_")] = tri
+        if f == "crystalpillar.obj":  # the 64 stale-index faces and their positions
+            idx = np.nonzero(tri[:, 27] == 0)[0]
+            keep["crystalpillar_flat_index"] = idx.astype(np.int32)
+            keep["crystalpillar_flat"] = tri[idx]
+    np.savez_compressed(os.path.join(GOLD, "meshes.npz"), meta=json.dumps(meta), **keep)
+
+
+def scene_rays(scene, n, seed):
+    """primary-like rays from the scene camera + rays between random points of the scene box"""
+    rng = np.random.default_rng(seed)
+    cam = scene.camera
+    o = np.array(cam.origin[:], np.float64)
+    R = np.array(cam.rot[:], np.float64).reshape(4, 4).T[:3, :3]  # column-major -> matrix
+    d = np.stack([rng.uniform(-1.3, 1.3, n // 2), rng.uniform(-1, 1, n // 2), np.full(n // 2, cam.dz)], -1) @ R.T
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    prim = np.concatenate([np.broadcast_to(o, d.shape), d], 1)
+    if scene.name == "competition":
+        lo, hi = np.array([-1.8, -0.7, 0.4]), np.array([0.6, 0.5, 1.8])
+    else:
+        lo, hi = np.array([-14.0, -2.9, 0.5]), np.array([14.0, 20.0, 29.0])
+    a, b = rng.uniform(lo, hi, (n - n // 2, 3)), rng.uniform(lo, hi, (n - n // 2, 3))
+    dd = (b - a) / np.linalg.norm(b - a, axis=1, keepdims=True)
+    return np.concatenate([prim, np.concatenate([a, dd], 1)]).astype(np.float32)
+
+
+def gen_rays(tmp):
+    for name, n in (("sample", 4096), ("competition", 4096), ("bunny", 1024)):
+        scene = FlatScene.builtin(name, lazy=True)
+        rays = scene_rays(scene, n, seed=10 + len(name))
+        d = rays[:, 3:].astype(np.float32)
+        rays[:, 3:] = d / np.sqrt((d * d).sum(1, keepdims=True), dtype=np.float32)
+        rin, rout = os.path.join(tmp, "r.in"), os.path.join(tmp, "r.out")
+        rays.tofile(rin)
+        run(O2, "rays", name, rin, rout)
+        r = np.fromfile(rout, np.float32).reshape(-1, 32)
+        ids = np.stack([r[:, 1], r[:, 2]], -1).astype(np.int32)
+        ids[r[:, 0] == 0] = -1
+        np.savez_compressed(
+            os.path.join(GOLD, f"rays_{name}.npz"), rays=rays, hit=r[:, 0].astype(np.uint8), object=ids[:, 0],
+            triangle=ids[:, 1], prim=ids_to_prim(ids, scene), distance=r[:, 3], intersection=r[:, 4:7], normal=r[:, 7:10],
+            normal_shading=r[:, 10:13], uv=r[:, 13:15], tangent=r[:, 15:18], bitangent=r[:, 18:21],
+            shadow=r[:, 21:25].astype(np.uint8), color_d0=r[:, 25:28], color_d3=r[:, 28:31])
+
+
+RENDERS = [  # name, scene, w, h, spp, depth, seed
+    ("sample_320x210", "sample", 320, 210, 4, 3, 0),
+    ("competition_256x192", "competition", 256, 192, 4, 3, 0),
+    ("bunny_160x120", "bunny", 160, 120, 4, 3, 0),
+    ("sample_160x105_spp16", "sample", 160, 105, 16, 3, 7),
+    ("competition_96x72_spp16", "competition", 96, 72, 16, 3, 7),
+    ("sample_160x105_depth0", "sample", 160, 105, 4, 0, 0),
+    ("competition_100x70_depth1", "competition", 100, 70, 4, 1, 0),  # ragged tiles (100 = 6*16+4, 70 = 4*16+6)
+]
+
+
+def gen_renders(tmp, only=None):
+    timing = {}
+    for name, scene_name, w, h, spp, depth, seed in RENDERS:
+        if only and only != name:
+            continue
+        scene = FlatScene.builtin(scene_name, lazy=True)
+        pre = os.path.join(tmp, name)
+        info = run(O2, "render", scene_name, w, h, spp, depth, seed, pre, "ids")
+        rgb8 = np.fromfile(pre + ".rgb8.i32", np.int32).reshape(h, w, 3)
+        rgbf = np.fromfile(pre + ".rgbf.f32", np.float32).reshape(h, w, 3)
+        ids = np.fromfile(pre + ".ids.i32", np.int32).reshape(h, w, 2)
+        fast = run(OFAST, "render", scene_name, w, h, spp, depth, seed, pre + "_fast")
+        rgb8_fast = np.fromfile(pre + "_fast.rgb8.i32", np.int32).reshape(h, w, 3)
+        # NaN samples exist in the reference (garbage hits on degenerate triangles far outside their box, see
+        # DESIGN.md "known reference artefacts"): (int)NaN is INT_MIN there.  Keep a mask, store clipped bytes.
+        invalid = ((rgb8 < 0) | (rgb8 > 255)).any(axis=2) | np.isnan(rgbf).any(axis=2)
+        np.savez_compressed(os.path.join(GOLD, f"render_{name}.npz"), rgb8=np.clip(rgb8, 0, 255).astype(np.uint8), rgbf=rgbf,
+                            invalid=invalid,
+                            primid=ids_to_prim(ids, scene), rgb8_ofast=np.clip(rgb8_fast, 0, 255).astype(np.uint8),
+                            params=json.dumps(dict(scene=scene_name, width=w, height=h, spp=spp, depth=depth, seed=seed)))
+        timing[name] = dict(o2=info, ofast=fast)
+        print(name, "O2 %.2fs" % info["render_s"], "Ofast %.2fs" % fast["render_s"], flush=True)
+    return timing
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        if a.only in (None, "perlin"):
+            gen_perlin(tmp)
+        if a.only in (None, "textures"):
+            gen_textures(tmp)
+        if a.only in (None, "meshes"):
+            gen_meshes(tmp)
+        if a.only in (None, "rays"):
+            gen_rays(tmp)
+        if a.only is None or a.only.startswith(("render", "sample", "competition", "bunny")):
+            t = gen_renders(tmp, None if a.only in (None, "render") else a.only)
+            if a.only in (None, "render"):
+                with open(os.path.join(GOLD, "ref_timing.json"), "w") as f:
+                    json.dump(dict(host="authoring container, 8 threads, g++ 11.4", runs=t), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,240 @@
+// Scene.cpp -- flattening of the object list and the host side of render()/trace_ray().  See Scene.h.
+#include "Scene.h"
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+std::vector<Light *> lights;
+glm::vec3 ambient_light(0.7f);  // main.cpp:37
+std::vector<Object *> objects;
+
+static void rtCheck(int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + rt_last_error());
+}
+
+// ---- texture tags -----------------------------------------------------------------------------------
+static rt_context *g_tex_ctx = nullptr;
+void rt_set_host_texture_context(rt_context *ctx) { g_tex_ctx = ctx; }
+static glm::vec3 evalOnGpu(int id, glm::vec2 uv) {
+    rt_context *ctx = g_tex_ctx ? g_tex_ctx : defaultContext();
+    float in[2] = {uv.x, uv.y}, out[3];
+    rtCheck(rt_eval_texture(ctx, id, 1, in, out), "rt_eval_texture");
+    return glm::vec3(out[0], out[1], out[2]);
+}
+glm::vec3 perlinNormal(glm::vec2 uv) { return evalOnGpu(RT_TEX_PERLIN_NORMAL, uv); }
+glm::vec3 perlinWater(glm::vec2 uv) { return evalOnGpu(RT_TEX_PERLIN_WATER, uv); }
+glm::vec3 opal(glm::vec2 uv) { return evalOnGpu(RT_TEX_OPAL, uv); }
+glm::vec3 perlinTerrain(glm::vec2 uv) { return evalOnGpu(RT_TEX_PERLIN_TERRAIN, uv); }
+glm::vec3 perlinIceTerrain(glm::vec2 uv) { return evalOnGpu(RT_TEX_PERLIN_ICE_TERRAIN, uv); }
+glm::vec3 snowTerrain(glm::vec2 uv) { return evalOnGpu(RT_TEX_SNOW_TERRAIN, uv); }
+glm::vec3 qwilfishTexture(glm::vec2 uv) { return evalOnGpu(RT_TEX_QWILFISH, uv); }
+glm::vec3 colorAt(glm::vec2 uv) { return evalOnGpu(RT_TEX_BMP_COLOR, uv); }
+glm::vec3 normalAt(glm::vec2 uv) { return evalOnGpu(RT_TEX_BMP_NORMAL, uv); }
+float ambientOcclusionAt(glm::vec2 uv) { return evalOnGpu(RT_TEX_BMP_OCCLUSION, uv).x; }
+float roughnessAt(glm::vec2 uv) { return evalOnGpu(RT_TEX_BMP_ROUGHNESS, uv).x; }
+
+int rt_texture_id_of(glm::vec3 (*f)(glm::vec2)) {
+    if (f == nullptr) return RT_TEX_NONE;
+    if (f == &perlinNormal) return RT_TEX_PERLIN_NORMAL;
+    if (f == &perlinWater) return RT_TEX_PERLIN_WATER;
+    if (f == &opal) return RT_TEX_OPAL;
+    if (f == &perlinTerrain) return RT_TEX_PERLIN_TERRAIN;
+    if (f == &perlinIceTerrain) return RT_TEX_PERLIN_ICE_TERRAIN;
+    if (f == &snowTerrain) return RT_TEX_SNOW_TERRAIN;
+    if (f == &qwilfishTexture) return RT_TEX_QWILFISH;
+    if (f == &colorAt) return RT_TEX_BMP_COLOR;
+    if (f == &normalAt) return RT_TEX_BMP_NORMAL;
+    return -1;
+}
+int rt_texture_id_of(float (*f)(glm::vec2)) {
+    if (f == nullptr) return RT_TEX_NONE;
+    if (f == &roughnessAt) return RT_TEX_BMP_ROUGHNESS;
+    if (f == &ambientOcclusionAt) return RT_TEX_BMP_OCCLUSION;
+    return -1;
+}
+
+// ---- flattening -------------------------------------------------------------------------------------
+int FlatScene::addMaterial(const Material &m) {
+    rt_material r;
+    std::memset(&r, 0, sizeof r);
+    for (int k = 0; k < 3; k++) {
+        r.ambient[k] = m.ambient[k];
+        r.diffuse[k] = m.diffuse[k];
+        r.specular[k] = m.specular[k];
+    }
+    r.reflection = m.reflection;
+    r.refraction = m.refraction;
+    r.sigma = m.sigma;
+    r.shininess = m.shininess;
+    r.texture = rt_texture_id_of(m.texture);
+    r.has_normal_map = m.hasNormalMap ? 1 : 0;
+    r.normal_map = rt_texture_id_of(m.normalMap);
+    r.is_anisotropic = m.isAnisotropic ? 1 : 0;
+    r.alpha_x = m.alpha_x;
+    r.alpha_y = m.alpha_y;
+    r.has_img_texture = m.hasImgTexture ? 1 : 0;
+    r.roughness = rt_texture_id_of(m.roughness);
+    r.occlusion = rt_texture_id_of(m.occlusion);
+    if (r.texture < 0 || r.normal_map < 0 || r.roughness < 0 || r.occlusion < 0)
+        throw std::runtime_error("flatten: material points at a texture function the GPU renderer does not know");
+    if (r.has_normal_map && r.normal_map == RT_TEX_NONE)
+        throw std::runtime_error("flatten: hasNormalMap without a normalMap function");
+    if (r.has_img_texture && (r.roughness == RT_TEX_NONE || r.occlusion == RT_TEX_NONE))
+        throw std::runtime_error("flatten: hasImgTexture without roughness/occlusion functions");
+    auto isBmp = [](int id) { return id >= RT_TEX_BMP_COLOR && id <= RT_TEX_BMP_OCCLUSION; };
+    if (isBmp(r.texture) || isBmp(r.normal_map) || isBmp(r.roughness) || isBmp(r.occlusion)) uses_bmp = true;
+    for (size_t k = 0; k < materials.size(); k++)
+        if (std::memcmp(&materials[k], &r, sizeof r) == 0) return (int)k;
+    materials.push_back(r);
+    return (int)materials.size() - 1;
+}
+
+static void push3(std::vector<float> &v, const glm::vec3 &a) { v.push_back(a.x); v.push_back(a.y); v.push_back(a.z); }
+static void push2(std::vector<float> &v, const glm::vec2 &a) { v.push_back(a.x); v.push_back(a.y); }
+static void pushMat(std::vector<float> &v, const glm::mat4 &m) {
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) v.push_back(m[c][r]);
+}
+
+void Sphere::flatten(FlatScene &out, int object_id) const {
+    pushMat(out.sph_M, transformationMatrix);
+    pushMat(out.sph_Minv, inverseTransformationMatrix);
+    pushMat(out.sph_N, normalMatrix);
+    out.sph_object.push_back(object_id);
+}
+void Plane::flatten(FlatScene &out, int object_id) const {
+    push3(out.pl_point, point);
+    push3(out.pl_normal, normal);
+    out.pl_object.push_back(object_id);
+}
+void MeshLoader::flatten(FlatScene &out, int object_id) const {
+    for (const Triangle &t : triangles) {
+        push3(out.v0, t.vertexA); push3(out.v1, t.vertexB); push3(out.v2, t.vertexC);
+        push3(out.nA, t.normalA); push3(out.nB, t.normalB); push3(out.nC, t.normalC);
+        push2(out.tA, t.textureA); push2(out.tB, t.textureB); push2(out.tC, t.textureC);
+        out.tri_flags.push_back((t.vertexNormals ? 1u : 0u) | (t.vertexTextures ? 2u : 0u));
+        out.tri_object.push_back(object_id);
+    }
+}
+
+FlatScene flattenScene(const std::vector<Object *> &objs, const std::vector<Light *> &ls, glm::vec3 ambient) {
+    FlatScene s;
+    for (size_t o = 0; o < objs.size(); o++) {
+        s.object_material.push_back(s.addMaterial(objs[o]->material));
+        objs[o]->flatten(s, (int)o);
+    }
+    for (const Light *l : ls) {
+        push3(s.light_pos, l->position);
+        push3(s.light_color, l->color);
+    }
+    s.ambient[0] = ambient.x; s.ambient[1] = ambient.y; s.ambient[2] = ambient.z;
+    return s;
+}
+
+void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir) {
+    rtCheck(rt_set_materials(ctx, (int32_t)s.materials.size(), s.materials.data()), "rt_set_materials");
+    rtCheck(rt_set_object_materials(ctx, (int32_t)s.object_material.size(), s.object_material.data()), "rt_set_object_materials");
+    rtCheck(rt_set_triangles(ctx, s.triangleCount(), s.v0.data(), s.v1.data(), s.v2.data(), s.nA.data(), s.nB.data(),
+                             s.nC.data(), s.tA.data(), s.tB.data(), s.tC.data(), s.tri_flags.data(), s.tri_object.data()),
+            "rt_set_triangles");
+    rtCheck(rt_set_spheres(ctx, (int32_t)s.sph_object.size(), s.sph_M.data(), s.sph_Minv.data(), s.sph_N.data(), s.sph_object.data()), "rt_set_spheres");
+    rtCheck(rt_set_planes(ctx, (int32_t)s.pl_object.size(), s.pl_point.data(), s.pl_normal.data(), s.pl_object.data()), "rt_set_planes");
+    rtCheck(rt_set_lights(ctx, (int32_t)(s.light_pos.size() / 3), s.light_pos.data(), s.light_color.data(), s.ambient), "rt_set_lights");
+    if (s.uses_bmp) {  // Textures.h:168-171
+        const char *names[4] = {"basecolor.bmp", "normal.bmp", "roughness.bmp", "ambientOcclusion.bmp"};
+        for (int slot = 0; slot < 4; slot++) {
+            BmpImage img = readBmp(texture_dir + "/" + names[slot]);
+            rtCheck(rt_set_bmp(ctx, slot, img.width, img.height, img.channels, img.pixels.data()), "rt_set_bmp");
+        }
+    }
+    rtCheck(rt_commit(ctx), "rt_commit");
+}
+
+rt_context *defaultContext() {
+    static rt_context *ctx = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (!ctx) {
+        const char *e = std::getenv("RT_DEVICE");
+        rtCheck(rt_create(e ? std::atoi(e) : 0, &ctx), "rt_create");
+    }
+    return ctx;
+}
+
+// ---- render()/trace_ray(): the GPU stands where the tile loop stood ----------------------------------
+static const void *g_uploaded_key = nullptr;
+static size_t g_uploaded_count = 0;
+static void ensureUploaded(rt_context *ctx, const std::string &texture_dir) {
+    // re-upload whenever the object list changed identity/size (cheap heuristic; clearScene() resets it)
+    if (g_uploaded_key == (const void *)objects.data() && g_uploaded_count == objects.size() + 1000003 * lights.size()) return;
+    FlatScene s = flattenScene(objects, lights, ambient_light);
+    uploadScene(ctx, s, texture_dir);
+    rt_set_host_texture_context(ctx);
+    g_uploaded_key = (const void *)objects.data();
+    g_uploaded_count = objects.size() + 1000003 * lights.size();
+}
+
+rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
+    rt_context *ctx = defaultContext();
+    ensureUploaded(ctx, opt.textureDir);
+    rt_render_params p{};
+    p.width = image.getWidth();
+    p.height = image.getHeight();
+    p.spp = opt.spp;
+    p.max_depth = opt.maxDepth;
+    p.seed = opt.seed;
+    p.jitter_mode = opt.jitterMode;
+    p.tile_rank = 0;
+    p.tile_world = 1;
+    rt_camera cam = camera.toC();
+    std::vector<uint8_t> rgb8((size_t)3 * p.width * p.height);
+    rt_stats st{};
+    rtCheck(rt_render(ctx, &cam, &p, rgb8.data(), nullptr, nullptr, &st), "rt_render");
+    image.setAll(rgb8.data());
+    return st;
+}
+
+std::vector<glm::vec3> trace_rays(const std::vector<Ray> &rays, int bounces, std::vector<Hit> *hits) {
+    rt_context *ctx = defaultContext();
+    ensureUploaded(ctx, "./textures");
+    const size_t n = rays.size();
+    std::vector<float> in(6 * n), col(3 * n);
+    for (size_t k = 0; k < n; k++) {
+        in[6 * k + 0] = rays[k].origin.x; in[6 * k + 1] = rays[k].origin.y; in[6 * k + 2] = rays[k].origin.z;
+        in[6 * k + 3] = rays[k].direction.x; in[6 * k + 4] = rays[k].direction.y; in[6 * k + 5] = rays[k].direction.z;
+    }
+    std::vector<rt_hit> h(hits ? n : 0);
+    rtCheck(rt_trace_batch(ctx, (int64_t)n, in.data(), bounces, col.data(), hits ? h.data() : nullptr, nullptr, nullptr), "rt_trace_batch");
+    std::vector<glm::vec3> out(n);
+    for (size_t k = 0; k < n; k++) out[k] = glm::vec3(col[3 * k], col[3 * k + 1], col[3 * k + 2]);
+    if (hits) {
+        hits->resize(n);
+        for (size_t k = 0; k < n; k++) {
+            Hit &d = (*hits)[k];
+            const rt_hit &s = h[k];
+            d.hit = s.hit != 0;
+            d.distance = s.distance;
+            d.object = (s.object >= 0 && (size_t)s.object < objects.size()) ? objects[s.object] : nullptr;
+            d.triangle = s.triangle;
+            d.intersection = glm::vec3(s.intersection[0], s.intersection[1], s.intersection[2]);
+            d.normal = glm::vec3(s.normal[0], s.normal[1], s.normal[2]);
+            d.normalShading = glm::vec3(s.normal_shading[0], s.normal_shading[1], s.normal_shading[2]);
+            d.uv = glm::vec2(s.uv[0], s.uv[1]);
+            d.tangent = glm::vec3(s.tangent[0], s.tangent[1], s.tangent[2]);
+            d.bitangent = glm::vec3(s.bitangent[0], s.bitangent[1], s.bitangent[2]);
+        }
+    }
+    return out;
+}
+
+glm::vec3 trace_ray(Ray ray, int bounces) { return trace_rays({ray}, bounces)[0]; }
+
+void clearScene() {
+    for (Object *o : objects) delete o;
+    for (Light *l : lights) delete l;
+    objects.clear();
+    lights.clear();
+    ambient_light = glm::vec3(0.7f);
+    g_uploaded_key = nullptr;
+    g_uploaded_count = 0;
+}
