@@ -1,0 +1,706 @@
+// rt_abi.cpp -- implementation of the C ABI declared in include/rt_hip.h: context, scene upload, BVH commit, the
+// chunked wavefront render loop and the test hooks.  Host code only; kernels live in rt_kernels.hip.
+// There is no CPU rendering path in this library: every entry point that produces pixels, hits or texture
+// values launches HIP kernels and fails if no device is usable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.h"
+#include "rt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+#define HIPOK(expr)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        if (count <= n && p) return 0;
+        release();
+        if (count == 0) return 0;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+        }
+        n = count;
+        return 0;
+    }
+    int upload(const std::vector<T> &h) {
+        if (alloc(std::max<size_t>(h.size(), 1))) return 1;
+        if (!h.empty()) HIPOK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    RtLaunchCfg cfg;
+    // host-side scene as handed over through rt_set_*
+    std::vector<rt_material> materials;
+    std::vector<int32_t> object_material;
+    std::vector<float> v0, v1, v2, nA, nB, nC, tA, tB, tC;
+    std::vector<uint32_t> tri_flags;
+    std::vector<int32_t> tri_object;
+    std::vector<RtSphere> spheres;
+    std::vector<RtPlane> planes;
+    std::vector<RtLight> lights;
+    float ambient[3] = {0, 0, 0};
+    std::vector<uint8_t> bmp[4];
+    int bmp_w[4] = {0, 0, 0, 0}, bmp_h[4] = {0, 0, 0, 0}, bmp_c[4] = {0, 0, 0, 0};
+    // committed scene
+    bool committed = false;
+    RtBvh bvh;
+    std::vector<int64_t> mesh_first;  // per object: first global triangle index (or -1)
+    DevBuf<RtNode> d_nodes;
+    DevBuf<RtTriGeom> d_geom;
+    DevBuf<RtTriShade> d_shade;
+    DevBuf<RtSphere> d_spheres;
+    DevBuf<RtPlane> d_planes;
+    DevBuf<rt_material> d_materials;
+    DevBuf<int32_t> d_objmat;
+    DevBuf<RtLight> d_lights;
+    DevBuf<uint8_t> d_bmp[4];
+    RtSceneDev dev{};
+    // wavefront workspace (sized for one chunk, reused across calls)
+    size_t ws_samples = 0;
+    int ws_fanout = 0, ws_lights = 0;
+    DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shB, d_shC;
+    DevBuf<float> d_rayR[2];
+    DevBuf<float2> d_hits;
+    DevBuf<long long> d_accum;
+    DevBuf<uint32_t> d_counters, d_chunk_counters;
+    RtQueues q{};
+    // tile-major outputs of rt_render
+    DevBuf<uint8_t> d_t8, d_o8;
+    DevBuf<float> d_tf, d_of;
+    DevBuf<uint32_t> d_tp, d_op;
+};
+
+namespace {
+
+int bind(rt_context *ctx) {
+    HIPOK(hipSetDevice(ctx->device));
+    return 0;
+}
+
+int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights) {
+    const int fanout = 1 << std::min(std::max(max_depth, 0), 4);  // rays of the deepest level per primary sample (worst case)
+    n_lights = std::max(n_lights, 1);
+    if (samples <= ctx->ws_samples && fanout <= ctx->ws_fanout && n_lights <= ctx->ws_lights) return 0;
+    samples = std::max(samples, ctx->ws_samples);
+    const int fo = std::max(fanout, ctx->ws_fanout), nl = std::max(n_lights, ctx->ws_lights);
+    const size_t ray_cap = samples * fo, sh_cap = ray_cap * nl;
+    if (ray_cap >= (1ull << 32) || sh_cap >= (1ull << 32)) return fail("chunk too large: queue capacity exceeds 2^32 entries");
+    for (int k = 0; k < 2; k++) {
+        if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
+    }
+    if (ctx->d_hits.alloc(ray_cap + 1)) return 1;
+    if (ctx->d_shA.alloc(sh_cap) || ctx->d_shB.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
+    if (ctx->d_accum.alloc(samples * 3)) return 1;
+    if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
+    ctx->ws_samples = samples;
+    ctx->ws_fanout = fo;
+    ctx->ws_lights = nl;
+    RtQueues &q = ctx->q;
+    for (int k = 0; k < 2; k++) {
+        q.rayA[k] = ctx->d_rayA[k].p;
+        q.rayB[k] = ctx->d_rayB[k].p;
+        q.rayR[k] = ctx->d_rayR[k].p;
+    }
+    q.hits = ctx->d_hits.p;
+    q.shA = ctx->d_shA.p;
+    q.shB = ctx->d_shB.p;
+    q.shC = ctx->d_shC.p;
+    q.accum = ctx->d_accum.p;
+    q.counters = ctx->d_counters.p;
+    q.ray_cap = (uint32_t)ray_cap;
+    q.shadow_cap = (uint32_t)sh_cap;
+    return 0;
+}
+
+struct KernelTimer {  // optional per-kernel-class timing with HIP events on the launch stream
+    bool on = false;
+    hipStream_t stream = nullptr;
+    struct Span { hipEvent_t a, b; int cls; };
+    std::vector<Span> spans;
+    void begin(int cls) {
+        if (!on) return;
+        Span s;
+        (void)hipEventCreate(&s.a);
+        (void)hipEventCreate(&s.b);
+        s.cls = cls;
+        (void)hipEventRecord(s.a, stream);
+        spans.push_back(s);
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(spans.back().b, stream);
+    }
+    void collect(double *ms /*[5]*/) {
+        for (Span &s : spans) {
+            float t = 0;
+            (void)hipEventElapsedTime(&t, s.a, s.b);
+            ms[s.cls] += t;
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+        spans.clear();
+    }
+};
+
+void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
+    for (int d = 0; d <= max_depth && d < 16; d++) {
+        st->rays_closest += c[RT_CNT_RAYS0 + d];
+        st->rays_shadow += c[RT_CNT_SHADOW0 + d];
+    }
+    st->shadow_culled += c[RT_CNT_CULLED];
+    st->hits_shaded += c[RT_CNT_SHADED];
+    st->queue_overflow += c[RT_CNT_OVERFLOW];
+    st->nodes_visited += ((uint64_t)c[RT_CNT_NODES_HI] << 32) | c[RT_CNT_NODES_LO];
+    st->tris_tested += ((uint64_t)c[RT_CNT_TRIS_HI] << 32) | c[RT_CNT_TRIS_LO];
+}
+
+// levels 0..max_depth of one chunk whose level-0 queue has already been filled
+void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
+               bool stats, KernelTimer &kt, rt_stats *st) {
+    for (int level = 0; level <= max_depth; level++) {
+        kt.begin(1);
+        rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
+        kt.end();
+        kt.begin(2);
+        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles);
+        kt.end();
+        kt.begin(3);
+        rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
+        kt.end();
+        if (st) {
+            st->launches_closest++;
+            st->launches_any++;
+        }
+    }
+}
+
+int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *d_rgb8, float *d_rgbf,
+                uint32_t *d_primid, hipStream_t stream, rt_stats *stats) {
+    if (!ctx->committed) return fail("rt_commit has not been called");
+    if (p->width <= 0 || p->height <= 0 || p->spp <= 0 || p->max_depth < 0 || p->max_depth > 15)
+        return fail("bad render parameters (width/height/spp > 0, 0 <= max_depth <= 15)");
+    const int world = p->tile_world > 0 ? p->tile_world : 1;
+    if (p->tile_rank < 0 || p->tile_rank >= world) return fail("tile_rank out of range");
+    const bool table = p->jitter_mode == RT_JITTER_TABLE || (p->jitter_mode == RT_JITTER_AUTO && p->spp == 4);
+    if (table && p->spp != 4) return fail("RT_JITTER_TABLE requires spp == 4 (reference jitterMatrix, main.cpp:601-606)");
+    if (bind(ctx)) return 1;
+
+    RtFrameDev f{};
+    std::memcpy(f.origin, cam->origin, sizeof f.origin);
+    std::memcpy(f.rot, cam->rot, sizeof f.rot);
+    f.dz = cam->dz;
+    // main.cpp:561-563: computed in double, stored as float
+    const float fov = cam->fov_deg;
+    const float s = 2 * tan(0.5 * fov / 180 * M_PI) / p->width;
+    f.s = s;
+    f.X = -s * p->width / 2;
+    f.Y = s * p->height / 2;
+    f.width = p->width;
+    f.height = p->height;
+    f.spp = p->spp;
+    f.tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
+    f.tile_rank = p->tile_rank;
+    f.tile_world = world;
+    f.use_table = table ? 1 : 0;
+    f.seed = p->seed;
+
+    int64_t n_local = 0, n_total = 0;
+    rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, &n_total);
+    const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
+    size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 21;
+    chunk_samples = std::min<size_t>(chunk_samples, RT_SAMPLE_MASK);
+    size_t chunk_tiles = std::max<size_t>(1, chunk_samples / per_tile);
+    chunk_tiles = std::min<size_t>(chunk_tiles, std::max<int64_t>(n_local, 1));
+    if (chunk_tiles * per_tile > RT_SAMPLE_MASK) return fail("spp too large for one tile per chunk");
+    if (ensureWorkspace(ctx, chunk_tiles * per_tile, p->max_depth, (int)ctx->lights.size())) return 1;
+    const size_t n_chunks = n_local ? (size_t)((n_local + chunk_tiles - 1) / chunk_tiles) : 0;
+    if (ctx->d_chunk_counters.alloc(std::max<size_t>(n_chunks, 1) * RT_CNT_WORDS)) return 1;
+
+    RtLaunchCfg cfg = ctx->cfg;
+    cfg.stream = stream;
+    const bool stats_on = (p->collect_stats & 1) != 0;
+    KernelTimer kt;
+    kt.on = (p->collect_stats & 2) != 0;
+    kt.stream = stream;
+    rt_stats local{};
+    rt_stats *st = stats ? stats : &local;
+    std::memset(st, 0, sizeof *st);
+
+    hipEvent_t ev0, ev1;
+    HIPOK(hipEventCreate(&ev0));
+    HIPOK(hipEventCreate(&ev1));
+    HIPOK(hipEventRecord(ev0, stream));
+    if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
+    for (size_t c = 0; c < n_chunks; c++) {
+        const uint32_t tile0 = (uint32_t)(c * chunk_tiles);
+        const uint32_t ntiles = (uint32_t)std::min<size_t>(chunk_tiles, (size_t)n_local - tile0);
+        HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
+        HIPOK(hipMemsetAsync(ctx->q.accum, 0, (size_t)ntiles * per_tile * 3 * sizeof(long long), stream));
+        kt.begin(0);
+        rtLaunchGenPrimary(cfg, f, ctx->q, tile0, ntiles);
+        kt.end();
+        runLevels(ctx, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st);
+        kt.begin(4);
+        rtLaunchResolve(cfg, f, ctx->q, tile0, ntiles, d_rgb8, d_rgbf);
+        kt.end();
+        HIPOK(hipMemcpyAsync(ctx->d_chunk_counters.p + c * RT_CNT_WORDS, ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t),
+                             hipMemcpyDeviceToDevice, stream));
+    }
+    HIPOK(hipEventRecord(ev1, stream));
+    HIPOK(hipStreamSynchronize(stream));
+    HIPOK(hipGetLastError());
+    float ms = 0;
+    HIPOK(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    st->ms_total = ms;
+    double cls[5] = {0, 0, 0, 0, 0};
+    kt.collect(cls);
+    st->ms_gen = cls[0]; st->ms_closest = cls[1]; st->ms_shade = cls[2]; st->ms_any = cls[3]; st->ms_resolve = cls[4];
+    std::vector<uint32_t> hc(std::max<size_t>(n_chunks, 1) * RT_CNT_WORDS, 0);
+    if (n_chunks) HIPOK(hipMemcpy(hc.data(), ctx->d_chunk_counters.p, n_chunks * RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < n_chunks; c++) addCounters(st, &hc[c * RT_CNT_WORDS], p->max_depth);
+    // primary samples = valid pixels of this rank's tiles x spp
+    {
+        uint64_t pix = 0;
+        const int tiles_x = f.tiles_x, tiles_y = (p->height + RT_TILE - 1) / RT_TILE;
+        for (int t = p->tile_rank; t < tiles_x * tiles_y; t += world) {
+            const int tx = t % tiles_x, ty = t / tiles_x;
+            pix += (uint64_t)std::min(RT_TILE, p->width - tx * RT_TILE) * std::min(RT_TILE, p->height - ty * RT_TILE);
+        }
+        st->primary_samples = pix * p->spp;
+    }
+    st->bvh_nodes = ctx->bvh.nodes.size();
+    st->bvh_depth = ctx->bvh.depth;
+    st->n_triangles = ctx->tri_flags.size();
+    if (st->queue_overflow) return fail("wavefront queue overflow (" + std::to_string(st->queue_overflow) + " rays dropped)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_err.c_str(); }
+
+int rt_create(int device_id, rt_context **out) {
+    if (!out) return fail("rt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail("rt_create: no HIP device available (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail("rt_create: device_id out of range");
+    HIPOK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPOK(hipGetDeviceProperties(&prop, device_id));
+    rt_context *ctx = new rt_context();
+    ctx->device = device_id;
+    ctx->cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail("rt_create: hipStreamCreate failed");
+    }
+    *out = ctx;
+    return 0;
+}
+
+int rt_destroy(rt_context *ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ctx->d_nodes.release(); ctx->d_geom.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
+    ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
+    for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
+    for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
+    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shB.release(); ctx->d_shC.release(); ctx->d_accum.release();
+    ctx->d_counters.release(); ctx->d_chunk_counters.release();
+    ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int rt_set_materials(rt_context *ctx, int32_t n, const rt_material *m) {
+    if (!ctx || n < 0 || (n && !m)) return fail("rt_set_materials: bad arguments");
+    for (int k = 0; k < n; k++) {
+        const int ids[4] = {m[k].texture, m[k].normal_map, m[k].roughness, m[k].occlusion};
+        for (int id : ids)
+            if (id < 0 || id >= RT_TEX_COUNT) return fail("rt_set_materials: unknown texture id");
+        if (m[k].has_normal_map && m[k].normal_map == RT_TEX_NONE) return fail("rt_set_materials: has_normal_map without normal_map");
+        if (m[k].has_img_texture && (m[k].roughness == RT_TEX_NONE || m[k].occlusion == RT_TEX_NONE))
+            return fail("rt_set_materials: has_img_texture without roughness/occlusion");
+    }
+    ctx->materials.assign(m, m + n);
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_object_materials(rt_context *ctx, int32_t n, const int32_t *om) {
+    if (!ctx || n < 0 || (n && !om)) return fail("rt_set_object_materials: bad arguments");
+    ctx->object_material.assign(om, om + n);
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_triangles(rt_context *ctx, int64_t n, const float *v0, const float *v1, const float *v2, const float *nA,
+                     const float *nB, const float *nC, const float *tA, const float *tB, const float *tC,
+                     const uint32_t *flags, const int32_t *object_id) {
+    if (!ctx || n < 0) return fail("rt_set_triangles: bad arguments");
+    if (n >= (1ll << 28)) return fail("rt_set_triangles: at most 2^28-1 triangles");
+    if (n && (!v0 || !v1 || !v2 || !flags || !object_id)) return fail("rt_set_triangles: NULL vertex/flags/object arrays");
+    auto put = [&](std::vector<float> &dst, const float *src, int w) {
+        dst.assign((size_t)n * w, 0.0f);
+        if (src && n) std::memcpy(dst.data(), src, (size_t)n * w * sizeof(float));
+    };
+    put(ctx->v0, v0, 3); put(ctx->v1, v1, 3); put(ctx->v2, v2, 3);
+    put(ctx->nA, nA, 3); put(ctx->nB, nB, 3); put(ctx->nC, nC, 3);
+    put(ctx->tA, tA, 2); put(ctx->tB, tB, 2); put(ctx->tC, tC, 2);
+    ctx->tri_flags.assign(flags, flags + n);
+    ctx->tri_object.assign(object_id, object_id + n);
+    for (int64_t k = 1; k < n; k++)
+        if (object_id[k] < object_id[k - 1]) return fail("rt_set_triangles: object_id must be non-decreasing");
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_spheres(rt_context *ctx, int32_t n, const float *M, const float *Minv, const float *Nmat, const int32_t *object_id) {
+    if (!ctx || n < 0 || n > RT_MAX_SPHERES || (n && (!M || !Minv || !Nmat || !object_id))) return fail("rt_set_spheres: bad arguments (at most 64 spheres)");
+    ctx->spheres.resize(n);
+    for (int k = 0; k < n; k++) {
+        RtSphere &s = ctx->spheres[k];
+        std::memcpy(s.M, M + 16 * k, 64);
+        std::memcpy(s.Minv, Minv + 16 * k, 64);
+        std::memcpy(s.N, Nmat + 16 * k, 64);
+        s.object = object_id[k];
+        s.material = 0;
+        s._pad[0] = s._pad[1] = 0;
+    }
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_planes(rt_context *ctx, int32_t n, const float *point, const float *normal, const int32_t *object_id) {
+    if (!ctx || n < 0 || n > RT_MAX_PLANES || (n && (!point || !normal || !object_id))) return fail("rt_set_planes: bad arguments (at most 64 planes)");
+    ctx->planes.resize(n);
+    for (int k = 0; k < n; k++) {
+        RtPlane &p = ctx->planes[k];
+        std::memcpy(p.point, point + 3 * k, 12);
+        std::memcpy(p.normal, normal + 3 * k, 12);
+        p.object = object_id[k];
+        p.material = 0;
+    }
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_lights(rt_context *ctx, int32_t n, const float *position, const float *color, const float *ambient) {
+    if (!ctx || n < 0 || n > 32 || (n && (!position || !color))) return fail("rt_set_lights: bad arguments (at most 32 lights)");
+    ctx->lights.resize(n);
+    for (int k = 0; k < n; k++) {
+        RtLight &l = ctx->lights[k];
+        std::memcpy(l.pos, position + 3 * k, 12);
+        std::memcpy(l.color, color + 3 * k, 12);
+        l._p0 = l._p1 = 0;
+    }
+    if (ambient) std::memcpy(ctx->ambient, ambient, 12);
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_bmp(rt_context *ctx, int32_t slot, int32_t w, int32_t h, int32_t c, const uint8_t *bytes) {
+    if (!ctx || slot < 0 || slot > 3 || w <= 0 || h <= 0 || c < 3 || c > 4 || !bytes) return fail("rt_set_bmp: bad arguments (24/32-bit images, slot 0..3)");
+    if (w > 65535 || h > 65535) return fail("rt_set_bmp: image larger than the reference's uint16 texel index");
+    ctx->bmp[slot].assign(bytes, bytes + (size_t)w * h * c);
+    ctx->bmp_w[slot] = w; ctx->bmp_h[slot] = h; ctx->bmp_c[slot] = c;
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_commit(rt_context *ctx) {
+    if (!ctx) return fail("rt_commit: NULL context");
+    if (bind(ctx)) return 1;
+    const int n_obj = (int)ctx->object_material.size(), n_mat = (int)ctx->materials.size();
+    const int64_t nt = (int64_t)ctx->tri_flags.size();
+    for (int m : ctx->object_material)
+        if (m < 0 || m >= n_mat) return fail("rt_commit: object refers to a material that was not set");
+    auto objOk = [&](int o) { return o >= 0 && o < n_obj; };
+    for (int64_t k = 0; k < nt; k++)
+        if (!objOk(ctx->tri_object[k])) return fail("rt_commit: triangle object_id out of range");
+    for (RtSphere &s : ctx->spheres) {
+        if (!objOk(s.object)) return fail("rt_commit: sphere object_id out of range");
+        s.material = ctx->object_material[s.object];
+    }
+    for (RtPlane &p : ctx->planes) {
+        if (!objOk(p.object)) return fail("rt_commit: plane object_id out of range");
+        p.material = ctx->object_material[p.object];
+    }
+    bool needs_bmp[4] = {false, false, false, false};
+    for (const rt_material &m : ctx->materials) {
+        const int ids[4] = {m.texture, m.has_normal_map ? m.normal_map : 0, m.has_img_texture ? m.roughness : 0, m.has_img_texture ? m.occlusion : 0};
+        for (int id : ids)
+            if (id >= RT_TEX_BMP_COLOR) needs_bmp[id - RT_TEX_BMP_COLOR] = true;
+    }
+    for (int k = 0; k < 4; k++)
+        if (needs_bmp[k] && ctx->bmp_w[k] == 0) return fail("rt_commit: a material samples a BMP map that was not set (rt_set_bmp)");
+
+    // acceleration structure + reordered triangle records
+    rtBuildBvh(nt, ctx->v0.data(), ctx->v1.data(), ctx->v2.data(), ctx->bvh);
+    std::vector<uint32_t> rank((size_t)nt);
+    rtReferenceOrder(nt, ctx->v0.data(), ctx->v1.data(), ctx->v2.data(), ctx->tri_object.data(), rank.data());
+    ctx->mesh_first.assign(n_obj, -1);
+    for (int64_t k = nt - 1; k >= 0; k--) ctx->mesh_first[ctx->tri_object[k]] = k;
+    std::vector<RtTriGeom> geom((size_t)nt);
+    std::vector<RtTriShade> shade((size_t)nt);
+    for (int64_t slot = 0; slot < nt; slot++) {
+        const size_t t = ctx->bvh.order[slot];
+        const float *A = &ctx->v0[3 * t], *B = &ctx->v1[3 * t], *C = &ctx->v2[3 * t];
+        // Triangle ctor, MeshLoader.h:58: normal = normalize(cross(B - A, C - A)), glm operand order
+        const float e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+        const float cx = e1[1] * e2[2] - e2[1] * e1[2], cy = e1[2] * e2[0] - e2[2] * e1[0], cz = e1[0] * e2[1] - e2[0] * e1[1];
+        const float xx = cx * cx, yy = cy * cy, zz = cz * cz;
+        const float inv = 1.0f / std::sqrt(xx + yy + zz);
+        RtTriGeom &g = geom[slot];
+        g.q0[0] = A[0]; g.q0[1] = A[1]; g.q0[2] = A[2]; g.q0[3] = cx * inv;
+        g.q1[0] = B[0]; g.q1[1] = B[1]; g.q1[2] = B[2]; g.q1[3] = cy * inv;
+        g.q2[0] = C[0]; g.q2[1] = C[1]; g.q2[2] = C[2]; g.q2[3] = cz * inv;
+        RtTriShade &s = shade[slot];
+        std::memcpy(s.nA, &ctx->nA[3 * t], 12); std::memcpy(s.nB, &ctx->nB[3 * t], 12); std::memcpy(s.nC, &ctx->nC[3 * t], 12);
+        std::memcpy(s.tA, &ctx->tA[2 * t], 8); std::memcpy(s.tB, &ctx->tB[2 * t], 8); std::memcpy(s.tC, &ctx->tC[2 * t], 8);
+        s.flags = ctx->tri_flags[t];
+        s.object = ctx->tri_object[t];
+        s.prim = (uint32_t)t;
+        s.rank = rank[t];
+        s._pad = 0;
+    }
+    if (ctx->d_nodes.upload(ctx->bvh.nodes) || ctx->d_geom.upload(geom) || ctx->d_shade.upload(shade)) return 1;
+    if (ctx->d_spheres.upload(ctx->spheres) || ctx->d_planes.upload(ctx->planes)) return 1;
+    if (ctx->d_materials.upload(ctx->materials) || ctx->d_objmat.upload(ctx->object_material) || ctx->d_lights.upload(ctx->lights)) return 1;
+    RtSceneDev &d = ctx->dev;
+    std::memset(&d, 0, sizeof d);
+    for (int k = 0; k < 4; k++) {
+        if (ctx->bmp_w[k]) {
+            if (ctx->d_bmp[k].upload(ctx->bmp[k])) return 1;
+            d.bmp[k] = ctx->d_bmp[k].p;
+        }
+        d.bmp_w[k] = ctx->bmp_w[k]; d.bmp_h[k] = ctx->bmp_h[k]; d.bmp_c[k] = ctx->bmp_c[k];
+    }
+    d.nodes = ctx->d_nodes.p;
+    d.tri_geom = ctx->d_geom.p;
+    d.tri_shade = ctx->d_shade.p;
+    d.spheres = ctx->d_spheres.p;
+    d.planes = ctx->d_planes.p;
+    d.materials = ctx->d_materials.p;
+    d.object_material = ctx->d_objmat.p;
+    d.lights = ctx->d_lights.p;
+    std::memcpy(d.ambient, ctx->ambient, 12);
+    d.n_nodes = (int)ctx->bvh.nodes.size();
+    d.n_tris = (int)nt;
+    d.n_spheres = (int)ctx->spheres.size();
+    d.n_planes = (int)ctx->planes.size();
+    d.n_lights = (int)ctx->lights.size();
+    d.n_objects = n_obj;
+    d.n_materials = n_mat;
+    // LDS traversal stack: entries >= tree depth; 256 B per entry per wave, 160 KB per CU
+    int entries = 8;
+    while (entries < ctx->bvh.depth + 1) entries += 8;
+    if (entries > 160) return fail("rt_commit: BVH deeper than the LDS stack budget");
+    ctx->cfg.stack_entries = entries;
+    const int lds_per_block = entries * 256 * 4;
+    ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
+    ctx->committed = true;
+    return 0;
+}
+
+int rt_tile_counts(int32_t width, int32_t height, int32_t rank, int32_t world, int64_t *n_local, int64_t *n_total) {
+    if (width <= 0 || height <= 0 || world <= 0 || rank < 0 || rank >= world) return fail("rt_tile_counts: bad arguments");
+    const int64_t tiles = (int64_t)((width + RT_TILE - 1) / RT_TILE) * ((height + RT_TILE - 1) / RT_TILE);
+    if (n_total) *n_total = tiles;
+    if (n_local) *n_local = tiles > rank ? (tiles - rank + world - 1) / world : 0;
+    return 0;
+}
+
+int rt_render_tiles_device(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8, void *d_rgbf,
+                           void *d_primid, void *stream, rt_stats *stats) {
+    if (!ctx || !cam || !p) return fail("rt_render_tiles_device: NULL argument");
+    return renderTiles(ctx, cam, p, (uint8_t *)d_rgb8, (float *)d_rgbf, (uint32_t *)d_primid,
+                       stream ? (hipStream_t)stream : ctx->stream, stats);
+}
+
+int rt_assemble_tiles_device(rt_context *ctx, int32_t width, int32_t height, int32_t world, int64_t tiles_per_rank,
+                             const void *t8, const void *tf, const void *tp, void *o8, void *of, void *op, void *stream) {
+    if (!ctx || width <= 0 || height <= 0 || world <= 0) return fail("rt_assemble_tiles_device: bad arguments");
+    int64_t need = 0;
+    rt_tile_counts(width, height, 0, world, &need, nullptr);
+    if (tiles_per_rank < need) return fail("rt_assemble_tiles_device: tiles_per_rank smaller than rank 0's tile count");
+    if (bind(ctx)) return 1;
+    RtLaunchCfg cfg = ctx->cfg;
+    cfg.stream = stream ? (hipStream_t)stream : ctx->stream;
+    rtLaunchAssemble(cfg, width, height, world, tiles_per_rank, t8, tf, tp, o8, of, op);
+    HIPOK(hipStreamSynchronize(cfg.stream));
+    HIPOK(hipGetLastError());
+    return 0;
+}
+
+int rt_render(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8, float *out_rgbf,
+              uint32_t *out_primid, rt_stats *stats) {
+    if (!ctx || !cam || !p) return fail("rt_render: NULL argument");
+    if (p->tile_world > 1) return fail("rt_render renders whole images; use rt_render_tiles_device for tile_world > 1");
+    if (bind(ctx)) return 1;
+    int64_t n_local = 0;
+    if (rt_tile_counts(p->width, p->height, 0, 1, &n_local, nullptr)) return 1;
+    const size_t tpix = (size_t)n_local * RT_TILE_PIXELS, npix = (size_t)p->width * p->height;
+    if (ctx->d_t8.alloc(tpix * 3) || ctx->d_tf.alloc(tpix * 3) || ctx->d_tp.alloc(tpix)) return 1;
+    if (ctx->d_o8.alloc(npix * 3) || ctx->d_of.alloc(npix * 3) || ctx->d_op.alloc(npix)) return 1;
+    rt_render_params q = *p;
+    q.tile_rank = 0;
+    q.tile_world = 1;
+    if (renderTiles(ctx, cam, &q, ctx->d_t8.p, ctx->d_tf.p, ctx->d_tp.p, ctx->stream, stats)) return 1;
+    if (rt_assemble_tiles_device(ctx, p->width, p->height, 1, n_local, ctx->d_t8.p, ctx->d_tf.p, ctx->d_tp.p, ctx->d_o8.p,
+                                 ctx->d_of.p, ctx->d_op.p, ctx->stream))
+        return 1;
+    if (out_rgb8) HIPOK(hipMemcpy(out_rgb8, ctx->d_o8.p, npix * 3, hipMemcpyDeviceToHost));
+    if (out_rgbf) HIPOK(hipMemcpy(out_rgbf, ctx->d_of.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_primid) HIPOK(hipMemcpy(out_primid, ctx->d_op.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, float *out_color, rt_hit *out_hits,
+                   uint8_t *out_shadow, rt_stats *stats) {
+    if (!ctx || n < 0 || (n && !rays) || depth < 0 || depth > 15) return fail("rt_trace_batch: bad arguments");
+    if (!ctx->committed) return fail("rt_commit has not been called");
+    if (bind(ctx)) return 1;
+    rt_stats local{};
+    rt_stats *st = stats ? stats : &local;
+    std::memset(st, 0, sizeof *st);
+    const size_t chunk = 1 << 20;
+    if (ensureWorkspace(ctx, std::min<size_t>(std::max<int64_t>(n, 1), chunk), depth, (int)ctx->lights.size())) return 1;
+    RtLaunchCfg cfg = ctx->cfg;
+    cfg.stream = ctx->stream;
+    DevBuf<float> d_rays, d_col;
+    DevBuf<rt_hit> d_hits;
+    DevBuf<uint8_t> d_sh;
+    KernelTimer kt;
+    int rc = 0;
+    for (int64_t off = 0; off < n && !rc; off += (int64_t)chunk) {
+        const uint32_t m = (uint32_t)std::min<int64_t>(chunk, n - off);
+        rc = d_rays.alloc((size_t)m * 6) || d_col.alloc((size_t)m * 3) || d_hits.alloc(m) || d_sh.alloc((size_t)m * 4);
+        if (rc) break;
+        hipError_t e = hipMemcpyAsync(d_rays.p, rays + 6 * off, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice, cfg.stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), cfg.stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ctx->q.accum, 0, (size_t)m * 3 * sizeof(long long), cfg.stream);
+        if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
+        rtLaunchRaysFromHost(cfg, d_rays.p, m, ctx->q);
+        // level 0 closest hit first: the hit records of the batch are reported from it
+        rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, false);
+        if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
+        runLevels(ctx, cfg, depth, 1, 0, nullptr, false, kt, st);
+        rtLaunchBatchColors(cfg, ctx->q, m, d_col.p);
+        std::vector<uint32_t> hc(RT_CNT_WORDS);
+        e = hipStreamSynchronize(cfg.stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(hc.data(), ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_color) e = hipMemcpy(out_color + 3 * off, d_col.p, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_hits) e = hipMemcpy(out_hits + off, d_hits.p, (size_t)m * sizeof(rt_hit), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_shadow) e = hipMemcpy(out_shadow + 4 * off, d_sh.p, (size_t)m * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
+        addCounters(st, hc.data(), depth);
+        if (out_hits) {  // slot -> triangle index inside its mesh
+            for (uint32_t k = 0; k < m; k++) {
+                rt_hit &h = out_hits[off + k];
+                if (h.hit && h.triangle >= 0) h.triangle = (int32_t)((int64_t)h.prim - ctx->mesh_first[h.object]);
+            }
+        }
+    }
+    d_rays.release(); d_col.release(); d_hits.release(); d_sh.release();
+    st->primary_samples = (uint64_t)n;
+    // the extra level-0 launch above is not double counted: runLevels re-traces level 0 into the same records
+    if (!rc && st->queue_overflow) rc = fail("wavefront queue overflow");
+    return rc;
+}
+
+int rt_eval_texture(rt_context *ctx, int32_t id, int64_t n, const float *uv, float *out) {
+    if (!ctx || n < 0 || id < 0 || id >= RT_TEX_COUNT || (n && (!uv || !out))) return fail("rt_eval_texture: bad arguments");
+    if (!ctx->committed && id >= RT_TEX_BMP_COLOR) return fail("rt_eval_texture: BMP maps need a committed scene");
+    if (bind(ctx)) return 1;
+    if (n == 0) return 0;
+    DevBuf<float> d_uv, d_out;
+    if (d_uv.alloc((size_t)n * 2) || d_out.alloc((size_t)n * 3)) return 1;
+    int rc = 0;
+    hipError_t e = hipMemcpy(d_uv.p, uv, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice);
+    RtLaunchCfg cfg = ctx->cfg;
+    cfg.stream = ctx->stream;
+    if (e == hipSuccess) {
+        rtLaunchEvalTexture(cfg, ctx->dev, id, n, d_uv.p, d_out.p);
+        e = hipStreamSynchronize(cfg.stream);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(hipGetErrorString(e));
+    d_uv.release();
+    d_out.release();
+    return rc;
+}
+
+int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out) {
+    if (!ctx || n < 0 || (n && (!p || !out))) return fail("rt_eval_perlin: bad arguments");
+    if (bind(ctx)) return 1;
+    if (n == 0) return 0;
+    DevBuf<float> d_p, d_out;
+    if (d_p.alloc((size_t)n * 3) || d_out.alloc((size_t)n)) return 1;
+    int rc = 0;
+    hipError_t e = hipMemcpy(d_p.p, p, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice);
+    RtLaunchCfg cfg = ctx->cfg;
+    cfg.stream = ctx->stream;
+    if (e == hipSuccess) {
+        rtLaunchEvalPerlin(cfg, n, d_p.p, d_out.p);
+        e = hipStreamSynchronize(cfg.stream);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(hipGetErrorString(e));
+    d_p.release();
+    d_out.release();
+    return rc;
+}
+
+int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order) {
+    if (!ctx || !ctx->committed) return fail("rt_get_bvh: no committed scene");
+    if (n_nodes) *n_nodes = (int64_t)ctx->bvh.nodes.size();
+    if (n_triangles) *n_triangles = (int64_t)ctx->bvh.order.size();
+    if (nodes && !ctx->bvh.nodes.empty()) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(RtNode));
+    if (tri_order && !ctx->bvh.order.empty()) std::memcpy(tri_order, ctx->bvh.order.data(), ctx->bvh.order.size() * sizeof(uint32_t));
+    return 0;
+}
+
+}  // extern "C"

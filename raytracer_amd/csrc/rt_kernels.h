@@ -1,0 +1,27 @@
+// rt_kernels.h -- host-callable launchers of the HIP kernels in rt_kernels.hip (internal to libraytracer_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rt_types.h"
+
+struct RtLaunchCfg {
+    hipStream_t stream = nullptr;
+    int num_cus = 256;             // from hipDeviceProp_t at rt_create
+    int stack_entries = 32;        // LDS traversal stack depth (>= BVH depth, chosen at rt_commit)
+    int trace_blocks_per_cu = 4;   // resident 256-thread blocks per CU for the traversal kernels (LDS-limited)
+};
+
+void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles);
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats);
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats);
+void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
+                   uint32_t tile0, uint32_t *primid_tiles);
+void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
+                     uint8_t *rgb8_tiles, float *rgbf_tiles);
+void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,
+                      const void *tf, const void *tp, void *o8, void *of, void *op);
+void rtLaunchHitInfo(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, uint32_t n,
+                     rt_hit *out_hits, uint8_t *out_shadow);
+void rtLaunchRaysFromHost(const RtLaunchCfg &cfg, const float *d_rays, uint32_t n, const RtQueues &q);
+void rtLaunchBatchColors(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t n, float *d_out);
+void rtLaunchEvalTexture(const RtLaunchCfg &cfg, const RtSceneDev &sc, int id, long long n, const float *d_uv, float *d_out);
+void rtLaunchEvalPerlin(const RtLaunchCfg &cfg, long long n, const float *d_p, float *d_out);

@@ -1,0 +1,691 @@
+// rt_kernels.hip -- the wavefront pipeline: hand-written HIP kernels for gfx950 (wave64).
+//
+//   k_gen_primary   SSAA primary rays of a chunk of tiles           (reference main.cpp:620-642)
+//   k_closest       closest hit: analytic prims + linear BVH        (closest main.cpp:59-71 and every intersect())
+//   k_shade         PhongModel minus its nested calls; emits shadow rays with their pending radiance and the
+//                   reflection / refraction pair of the next level  (main.cpp:81-213)
+//   k_any           shadow rays: early-out any-hit, adds the pending radiance when unoccluded (is_shadowed :41-57)
+//   k_resolve       per-sample clamp, mean, tone map, 8-bit truncation (main.cpp:232,646,240-256; Image.h:91-95)
+//   k_assemble      tile-major rank buffers -> row-major image (multi-GPU gather epilogue)
+//   k_hitinfo / k_eval_texture / k_eval_perlin   test hooks of the C ABI
+//
+// Queues are compacted with 64-wide ballots: one atomic per wave reserves a block, mbcnt gives the lane offset.
+// Traversal keeps a per-lane stack in LDS, laid out [entry][lane] so that a wave's push/pop is conflict-free.
+#include <hip/hip_runtime.h>
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+#define RT_BLOCK 256
+#define RT_NODE_LEAF 0x80000000u
+#define RT_NODE_DONE 0xFFFFFFFFu
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-level helpers
+RT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+RT_DEV uint32_t maskRankBelow(unsigned long long m) {  // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// all 64 lanes must call this together; `total` is wave-uniform.  Returns the wave's base slot (uniform).
+RT_DEV uint32_t waveReserve(uint32_t *counter, uint32_t total) {
+    uint32_t base = 0;
+    if (laneId() == 0 && total) base = atomicAdd(counter, total);
+    return __builtin_amdgcn_readfirstlane(base);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BVH traversal
+struct RtTraversalStats { uint32_t nodes, tris; };
+
+RT_DEV uint32_t nodeRef(float4 lo, float4 hi) {  // reference word of a node: inner -> child pair index, leaf -> packed range
+    const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
+    return b == 0 ? a : (RT_NODE_LEAF | ((b - 1u) << 28) | a);
+}
+
+// slab test against [tlo, thi]; entry distance in tnear.  Precomputed inv = 1/d and oi = o*inv (one fma per plane).
+RT_DEV bool slabHit(float4 lo, float4 hi, V3 inv, V3 oi, float thi, float &tnear) {
+    float ax = __builtin_fmaf(lo.x, inv.x, -oi.x), bx = __builtin_fmaf(hi.x, inv.x, -oi.x);
+    float ay = __builtin_fmaf(lo.y, inv.y, -oi.y), by = __builtin_fmaf(hi.y, inv.y, -oi.y);
+    float az = __builtin_fmaf(lo.z, inv.z, -oi.z), bz = __builtin_fmaf(hi.z, inv.z, -oi.z);
+    float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), thi));
+    tnear = tmin;
+    return tmin <= tmax * 1.0000005f;  // node boxes are also padded at build time (rt_bvh.cpp)
+}
+
+RT_DEV float safeInv(float d) {
+    // 1/d with |1/d| capped so that o*inv stays finite (a zero component must not turn the fma into inf-inf)
+    float inv = 1.0f / d;
+    const float cap = 1e30f;
+    if (!(fabsf(inv) <= cap)) inv = (__float_as_uint(d) >> 31) ? -cap : cap;
+    return inv;
+}
+
+// ANY = false: closest hit with the reference's tie rule; ANY = true: first hit with t <= tmax ends the walk.
+// `stack` points at this lane's column of the block's LDS stack (stride RT_BLOCK words).
+template <bool ANY, bool STATS>
+RT_DEV bool traverseBvh(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, float &best_t, uint32_t &best_id,
+                        uint32_t *stack, RtTraversalStats &st) {
+    if (sc.n_tris == 0) return false;
+    const V3 inv = v3(safeInv(r.d.x), safeInv(r.d.y), safeInv(r.d.z));
+    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
+    uint32_t cur = root_ref;
+    int sp = 0;
+    bool found = false;
+    while (cur != RT_NODE_DONE) {
+        while (!(cur & RT_NODE_LEAF)) {  // inner node: cur = index of its left child; the sibling pair is one 64-B line
+            const float4 l0 = nodes[2 * cur], l1 = nodes[2 * cur + 1], r0 = nodes[2 * cur + 2], r1 = nodes[2 * cur + 3];
+            if (STATS) st.nodes += 2;
+            float tl, tr;
+            const bool hl = slabHit(l0, l1, inv, oi, best_t, tl);
+            const bool hr = slabHit(r0, r1, inv, oi, best_t, tr);
+            const uint32_t rl = nodeRef(l0, l1), rr = nodeRef(r0, r1);
+            if (hl && hr) {
+                const bool leftFirst = tl <= tr;
+                stack[sp * RT_BLOCK] = leftFirst ? rr : rl;
+                sp++;
+                cur = leftFirst ? rl : rr;
+            } else if (hl) {
+                cur = rl;
+            } else if (hr) {
+                cur = rr;
+            } else {
+                cur = sp ? stack[(--sp) * RT_BLOCK] : RT_NODE_DONE;
+            }
+        }
+        if (cur != RT_NODE_DONE) {  // leaf
+            const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const uint32_t slot = first + k;
+                const RtTri T = rtLoadTri(sc.tri_geom, slot);
+                if (STATS) st.tris++;
+                float t;
+                if (!rtTriHit(T, r, best_t, t)) continue;
+                if (ANY) {
+                    found = true;
+                    break;
+                }
+                bool take = t < best_t;
+                if (!take && t == best_t) {
+                    // exact tie: the earlier object wins (main.cpp:67), inside a mesh the earlier candidate in the
+                    // reference's order wins (MeshLoader.h:399-404)
+                    const RtTriShade &s = sc.tri_shade[slot];
+                    unsigned long long mine = ((unsigned long long)(uint32_t)s.object << 32) | s.rank, theirs;
+                    const uint32_t kind = best_id & RT_ID_KIND_MASK;
+                    if (best_id == RT_ID_MISS) theirs = ~0ull;
+                    else if (kind == RT_ID_SPHERE) theirs = (unsigned long long)(uint32_t)sc.spheres[best_id & 0xFFFF].object << 32;
+                    else if (kind == RT_ID_PLANE) theirs = (unsigned long long)(uint32_t)sc.planes[best_id & 0xFFFF].object << 32;
+                    else theirs = ((unsigned long long)(uint32_t)sc.tri_shade[best_id].object << 32) | sc.tri_shade[best_id].rank;
+                    take = mine < theirs;
+                }
+                if (take) {
+                    best_t = t;
+                    best_id = slot;
+                    found = true;
+                }
+            }
+            if (ANY && found) break;
+            cur = sp ? stack[(--sp) * RT_BLOCK] : RT_NODE_DONE;
+        }
+    }
+    return found;
+}
+
+// closest(): analytic primitives in scene order, then the triangle BVH (ties resolved by object order above)
+template <bool STATS>
+RT_DEV void closestHit(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, float &best_t, uint32_t &best_id,
+                       uint32_t *stack, RtTraversalStats &st) {
+    best_t = INFINITY;
+    best_id = RT_ID_MISS;
+    int best_obj = 0x7FFFFFFF;
+    for (int k = 0; k < sc.n_spheres; k++) {
+        float dist;
+        V3 ni, P;
+        if (rtSphereHit(sc.spheres[k], r, dist, ni, P) && (dist < best_t || (dist == best_t && sc.spheres[k].object < best_obj))) {
+            best_t = dist;
+            best_id = RT_ID_SPHERE | (uint32_t)k;
+            best_obj = sc.spheres[k].object;
+        }
+    }
+    for (int k = 0; k < sc.n_planes; k++) {
+        float t;
+        if (rtPlaneHit(sc.planes[k], r, t) && (t < best_t || (t == best_t && sc.planes[k].object < best_obj))) {
+            best_t = t;
+            best_id = RT_ID_PLANE | (uint32_t)k;
+            best_obj = sc.planes[k].object;
+        }
+    }
+    traverseBvh<false, STATS>(sc, root_ref, r, best_t, best_id, stack, st);
+}
+
+// is_shadowed() after its back-face test: any object with hit.distance <= dist (main.cpp:50-55)
+template <bool STATS>
+RT_DEV bool occluded(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, float dist, uint32_t *stack, RtTraversalStats &st) {
+    for (int k = 0; k < sc.n_spheres; k++) {
+        float d;
+        V3 ni, P;
+        if (rtSphereHit(sc.spheres[k], r, d, ni, P) && d <= dist) return true;
+    }
+    for (int k = 0; k < sc.n_planes; k++) {
+        float t;
+        if (rtPlaneHit(sc.planes[k], r, t) && t <= dist) return true;
+    }
+    float tmax = dist;
+    uint32_t id = RT_ID_MISS;
+    return traverseBvh<true, STATS>(sc, root_ref, r, tmax, id, stack, st);
+}
+
+RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st) {
+    unsigned long long n = st.nodes, t = st.tris;
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off);
+        t += __shfl_down(t, off);
+    }
+    if (laneId() == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + RT_CNT_NODES_LO), n);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + RT_CNT_TRIS_LO), t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tile / sample indexing.  A chunk covers local tiles [tile0, tile0 + ntiles); sample index inside the chunk:
+//   ((tile - tile0) * 256 + m) * spp + s,   m = Morton index of the pixel inside its 16x16 tile
+// so that a wave's 64 lanes are 64/spp neighbouring pixels (a 4x4 block at 4 spp) x spp samples.
+RT_DEV uint32_t compact1By1(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x ^ (x >> 1)) & 0x33333333u;
+    x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+    x = (x ^ (x >> 4)) & 0x00ff00ffu;
+    return x;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues q, uint32_t tile0, uint32_t ntiles) {
+    const uint32_t total = ntiles * RT_TILE_PIXELS * (uint32_t)f.spp;
+    const uint32_t rounded = (total + 63u) & ~63u;
+    for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < rounded; idx += gridDim.x * RT_BLOCK) {
+        bool valid = idx < total;
+        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, 0);
+        if (valid) {
+            const uint32_t s = idx % (uint32_t)f.spp, pm = idx / (uint32_t)f.spp;
+            const uint32_t m = pm & 255u, lt = tile0 + (pm >> 8);
+            const uint32_t gt = lt * (uint32_t)f.tile_world + (uint32_t)f.tile_rank;
+            const int i = (int)((gt % (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m));
+            const int j = (int)((gt / (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m >> 1));
+            valid = i < f.width && j < f.height;
+            if (valid) {
+                float jx, jy;
+                if (f.use_table) {  // jitterMatrix, main.cpp:601-606 (selects, not an indexed array: no scratch)
+                    const uint32_t k = s & 3u;
+                    jx = k == 0 ? (float)(-1.0 / 4.0) : (k == 1 ? (float)(3.0 / 4.0) : (k == 2 ? (float)(-3.0 / 4.0) : (float)(1.0 / 4.0)));
+                    jy = k == 0 ? (float)(3.0 / 4.0) : (k == 1 ? (float)(1.0 / 3.0) : (k == 2 ? (float)(-1.0 / 4.0) : (float)(-3.0 / 4.0)));
+                } else {
+                    rtHashJitter((uint32_t)(j * f.width + i), s, f.seed, jx, jy);
+                }
+                const float dx = f.X + ((float)i + jx) * f.s + f.s / 2;  // main.cpp:629-630
+                const float dy = f.Y - ((float)j + jy) * f.s - f.s / 2;
+                const V3 d = normalize(mulPoint(f.rot, v3(dx, dy, f.dz), 0.0f));  // :637-641
+                A = make_float4(f.origin[0], f.origin[1], f.origin[2], 1.0f);
+                B = make_float4(d.x, d.y, d.z, __uint_as_float(idx));
+            }
+        }
+        const unsigned long long mask = __ballot(valid);
+        const uint32_t base = waveReserve(q.counters + RT_CNT_RAYS0, (uint32_t)__popcll(mask));
+        if (valid) {
+            const uint32_t slot = base + maskRankBelow(mask);
+            if (slot < q.ray_cap) {
+                q.rayA[0][slot] = A;
+                q.rayB[0][slot] = B;
+                q.rayR[0][slot] = 1.0f;
+            } else {
+                atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level) {
+    extern __shared__ uint32_t s_stack[];
+    uint32_t *stack = s_stack + threadIdx.x;
+    const int buf = level & 1;
+    const uint32_t n = min(q.counters[RT_CNT_RAYS0 + level], q.ray_cap);
+    RtTraversalStats st{0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const float4 A = q.rayA[buf][i], B = q.rayB[buf][i];
+        RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
+        float t;
+        uint32_t id;
+        closestHit<STATS>(sc, root_ref, r, t, id, stack, st);
+        q.hits[i] = make_float2(t, __uint_as_float(id));
+    }
+    if (STATS) flushStats(q.counters, st);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level) {
+    extern __shared__ uint32_t s_stack[];
+    uint32_t *stack = s_stack + threadIdx.x;
+    const uint32_t n = min(q.counters[RT_CNT_SHADOW0 + level], q.shadow_cap);
+    RtTraversalStats st{0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const float4 A = q.shA[i], B = q.shB[i];
+        RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
+        if (!occluded<STATS>(sc, root_ref, r, A.w, stack, st)) {
+            const float4 C = q.shC[i];
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * __float_as_uint(B.w);
+            atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
+            atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
+            atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
+        }
+    }
+    if (STATS) flushStats(q.counters, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PhongModel without its nested closest()/is_shadowed() calls (main.cpp:81-213).  One lane per traced ray of
+// `level`; remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
+// Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
+                                                   uint32_t tile0, uint32_t *primid_tiles) {
+    const int buf = level & 1, nbuf = buf ^ 1;
+    const uint32_t n = min(q.counters[RT_CNT_RAYS0 + level], q.ray_cap);
+    const uint32_t rounded = (n + 63u) & ~63u;
+    const int remaining = max_depth - level;
+    uint32_t culled = 0, shaded = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < rounded; i += gridDim.x * RT_BLOCK) {
+        bool active = i < n;
+        float2 hrec = make_float2(0.0f, __uint_as_float(RT_ID_MISS));
+        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, 0);
+        if (active) {
+            hrec = q.hits[i];
+            A = q.rayA[buf][i];
+            B = q.rayB[buf][i];
+        }
+        const uint32_t id = __float_as_uint(hrec.y);
+        const uint32_t sflags = __float_as_uint(B.w), sample = sflags & RT_SAMPLE_MASK;
+        if (active && level == 0 && primid_tiles && (sample % (uint32_t)spp) == 0) {
+            // primitive hit by sample 0 of the pixel, written tile-major at y*16+x
+            const uint32_t pm = sample / (uint32_t)spp, m = pm & 255u;
+            const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
+            uint32_t prim = RT_PRIM_MISS;
+            if (id != RT_ID_MISS) {
+                const uint32_t kind = id & RT_ID_KIND_MASK;
+                if (kind == RT_ID_SPHERE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.spheres[id & 0xFFFF].object;
+                else if (kind == RT_ID_PLANE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.planes[id & 0xFFFF].object;
+                else prim = sc.tri_shade[id].prim;
+            }
+            primid_tiles[(size_t)(tile0 + (pm >> 8)) * RT_TILE_PIXELS + py * RT_TILE + px] = prim;
+        }
+        active = active && id != RT_ID_MISS;
+
+        // per-lane state carried from the shading step to the (wave-uniform) emission steps
+        V3 P = v3s(0), ns = v3s(0), view = v3s(0), normal = v3s(0), dcol = v3s(0), mspec = v3s(0), hT = v3s(0), hB = v3s(0);
+        float weight = 0.0f, shiny = 0.0f, alpha_x = 1.0f, alpha_y = 1.0f, directScale = 1.0f, directScale2 = 1.0f;
+        bool aniso = false;
+        uint32_t litmask = 0;  // bit l: light l faces the surface (is_shadowed's back-face test, main.cpp:44-46)
+        bool emitRefl = false, emitRefr = false;
+        V3 reflDir = v3s(0), refrDir = v3s(0);
+        float wRefl = 0, wRefr = 0, fresnelR = 1.0f;
+        const int nlights = sc.n_lights;
+
+        if (active) {
+            shaded++;
+            weight = A.w;
+            if (sflags & RT_FLAG_HAS_REFR_SIBLING) {  // reflection *= R only if the refraction ray hit (main.cpp:187,201)
+                const bool sibHit = __float_as_uint(q.hits[i + 1].y) != RT_ID_MISS;
+                if (sibHit) weight = weight * q.rayR[buf][i];
+            }
+            RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
+            RtFullHit h;
+            rtReconstructHit(sc, r, hrec.x, id, h);
+            const rt_material m = sc.materials[h.material];
+            P = h.P;
+            hT = h.T;
+            hB = h.B;
+            view = normalize(-r.d);  // main.cpp:228
+            normal = h.normal;
+            ns = h.ns;
+            if (dot(normal, view) < 0) normal = -normal;  // main.cpp:88-94
+            if (dot(ns, view) < 0) ns = -ns;
+            mspec = ld3(m.specular);
+            aniso = m.is_anisotropic != 0;
+            alpha_x = m.alpha_x;
+            alpha_y = m.alpha_y;
+            // (1 - reflection)(1 - refraction) scaling of the direct term (main.cpp:153,172), only with budget left
+            const bool bounce = remaining > 0;
+            const bool hasRefl = bounce && m.reflection > 0, hasRefr = bounce && m.refraction > 0;
+            if (hasRefl) directScale = 1 - m.reflection;
+            if (hasRefr) directScale2 = 1 - m.refraction;
+
+            for (int l = 0; l < nlights; l++) {
+                const V3 ld = normalize(ld3(sc.lights[l].pos) - P);  // main.cpp:97
+                if (dot(normal, ld) < 0) culled++;
+                else litmask |= 1u << l;
+            }
+            if (litmask) {
+                // texture and roughness are light-independent: evaluated once (the reference re-evaluates per light)
+                dcol = m.texture != RT_TEX_NONE ? rtEvalTexture(sc, m.texture, h.uv) : ld3(m.diffuse);
+                shiny = m.shininess;
+                if (m.has_img_texture) {  // main.cpp:116-117, double pow
+                    const double rough = (double)rtEvalTexture(sc, m.roughness, h.uv).x;
+                    const double r2 = rough * rough;
+                    shiny = (float)((0.5 / (r2 * r2)) - 0.5);
+                }
+            }
+            // ambient term, added at every node and never scaled (main.cpp:207-211)
+            V3 amb;
+            if (m.has_img_texture) amb = ld3(sc.ambient) * 0.1f * rtEvalTexture(sc, m.occlusion, h.uv).x;
+            else amb = ld3(sc.ambient) * ld3(m.ambient);
+            amb = amb * weight;
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+            atomicAdd(acc + 0, (unsigned long long)rtToFixed(amb.x));
+            atomicAdd(acc + 1, (unsigned long long)rtToFixed(amb.y));
+            atomicAdd(acc + 2, (unsigned long long)rtToFixed(amb.z));
+
+            if (hasRefl) {  // main.cpp:152-166
+                reflDir = rtReflect(-view, ns);
+                wRefl = weight * m.reflection;
+                emitRefl = true;
+            }
+            if (hasRefr) {  // main.cpp:171-203
+                const bool entering = dot(ns, -view) < 0.0f;
+                const float n1 = entering ? 1.0f : m.sigma, n2 = entering ? m.sigma : 1.0f;
+                const float eta = n1 / n2;
+                if (rtRefract(-view, entering ? ns : -ns, eta, refrDir)) {
+                    const float O1 = cosf(rtAngle(ns, view));
+                    const float O2 = cosf(rtAngle(-ns, refrDir));
+                    const double ra = (double)((n1 * O1 - n2 * O2) / (n1 * O1 + n2 * O2));
+                    const double rb = (double)((n1 * O2 - n2 * O1) / (n1 * O2 + n2 * O1));
+                    fresnelR = (float)(0.5 * (ra * ra + rb * rb));
+                    const float T = 1 - fresnelR;
+                    wRefr = weight * m.refraction * T;
+                    emitRefr = true;
+                }
+            }
+        }
+
+        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  Lights are
+        // processed four at a time; emission is wave-compacted and light-major inside the wave so that a batch of
+        // shadow rays towards one light stays coherent for k_any.
+        for (int l0 = 0; l0 < nlights; l0 += 4) {
+            unsigned long long masks[4];
+            uint32_t total = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                masks[k] = __ballot((litmask >> (l0 + k)) & 1u);
+                total += (uint32_t)__popcll(masks[k]);
+            }
+            const uint32_t base = waveReserve(q.counters + RT_CNT_SHADOW0 + level, total);
+            uint32_t off = base;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = l0 + k;
+                if ((litmask >> l) & 1u) {
+                    const V3 lp = ld3(sc.lights[l].pos), lc = ld3(sc.lights[l].color);
+                    const V3 ld = normalize(lp - P);                     // main.cpp:97
+                    const float dl = length(lp - P);                     // :98
+                    const float diffuse = smax(0.0f, dot(ld, ns));       // :104
+                    const V3 hv = normalize(ld + view);                  // :106
+                    const float distance = smax(0.1f, dl);               // :109
+                    const float attenuation = (float)(1.0 / ((double)distance * (double)distance));  // :110 (double pow)
+                    const V3 diffusion = attenuation * lc * dcol * diffuse;
+                    V3 spec = v3s(0.0f);
+                    if (aniso) {  // main.cpp:123-139
+                        const float NdotL = dot(ns, ld), NdotV = dot(ns, view);
+                        if (NdotL > 0 && NdotV > 0) {
+                            const float HdotT = dot(hv, hT), HdotB = dot(hv, hB), HdotN = dot(hv, ns);
+                            const float e1 = HdotT / alpha_x, e2 = HdotB / alpha_y;
+                            const float exponent = -2.0f * (powf(e1, 2.0f) * powf(e2, 2.0f)) / (1 + HdotN);
+                            const float pi = 3.14159265358979323846264338327950288f;
+                            spec = (mspec * NdotL * expf(exponent)) / (sqrtf(NdotL * NdotV) * 4 * pi * alpha_x * alpha_y);
+                        }
+                    } else {  // :141-142; std::max(0.0f, NaN) == 0.0f
+                        const float specular = smax(0.0f, powf(dot(hv, ns), 4 * shiny));
+                        spec = attenuation * lc * mspec * specular;
+                    }
+                    V3 c = diffusion + spec;
+                    c = c * directScale;   // x * 1.0f is exact when no scaling applies
+                    c = c * directScale2;
+                    c = c * weight;
+                    const uint32_t slot = off + maskRankBelow(masks[k]);
+                    if (slot < q.shadow_cap) {
+                        const V3 so = P + RT_EPSILON * ld;  // main.cpp:49
+                        q.shA[slot] = make_float4(so.x, so.y, so.z, dl);
+                        q.shB[slot] = make_float4(ld.x, ld.y, ld.z, __uint_as_float(sample));
+                        q.shC[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+                    } else {
+                        atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+                    }
+                }
+                off += (uint32_t)__popcll(masks[k]);
+            }
+        }
+        // ---- next-level rays, lane-major so that a reflection/refraction pair stays adjacent ----
+        {
+            const unsigned long long mRefl = __ballot(emitRefl), mRefr = __ballot(emitRefr);
+            const uint32_t total = (uint32_t)(__popcll(mRefl) + __popcll(mRefr));
+            const uint32_t base = waveReserve(q.counters + RT_CNT_RAYS0 + level + 1, total);
+            uint32_t slot = base + maskRankBelow(mRefl) + maskRankBelow(mRefr);
+            if (emitRefl) {
+                if (slot < q.ray_cap) {
+                    const V3 ro = P + RT_EPSILON * reflDir;  // main.cpp:155
+                    q.rayA[nbuf][slot] = make_float4(ro.x, ro.y, ro.z, wRefl);
+                    q.rayB[nbuf][slot] = make_float4(reflDir.x, reflDir.y, reflDir.z,
+                                                     __uint_as_float(sample | (emitRefr ? RT_FLAG_HAS_REFR_SIBLING : 0u)));
+                    q.rayR[nbuf][slot] = fresnelR;
+                } else {
+                    atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+                }
+                slot++;
+            }
+            if (emitRefr) {
+                if (slot < q.ray_cap) {
+                    const V3 ro = P + RT_EPSILON * refrDir;  // main.cpp:181
+                    q.rayA[nbuf][slot] = make_float4(ro.x, ro.y, ro.z, wRefr);
+                    q.rayB[nbuf][slot] = make_float4(refrDir.x, refrDir.y, refrDir.z, __uint_as_float(sample));
+                    q.rayR[nbuf][slot] = 1.0f;
+                } else {
+                    atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+                }
+            }
+        }
+    }
+    // statistics: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        culled += __shfl_down(culled, off);
+        shaded += __shfl_down(shaded, off);
+    }
+    if (laneId() == 0) {
+        if (culled) atomicAdd(q.counters + RT_CNT_CULLED, culled);
+        if (shaded) atomicAdd(q.counters + RT_CNT_SHADED, shaded);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// trace_ray's clamp per SAMPLE (main.cpp:232), mean over samples (:646), toneMapping (:240-256),
+// Image::setPixel truncation (Image.h:91-95).  One lane per pixel slot of the chunk; outputs are tile-major.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(RtFrameDev f, RtQueues q, uint32_t tile0, uint32_t ntiles,
+                                                     uint8_t *rgb8_tiles, float *rgbf_tiles) {
+    const uint32_t total = ntiles * RT_TILE_PIXELS;
+    for (uint32_t pm = blockIdx.x * RT_BLOCK + threadIdx.x; pm < total; pm += gridDim.x * RT_BLOCK) {
+        const uint32_t m = pm & 255u;
+        const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
+        V3 sum = v3s(0.0f);
+        for (int s = 0; s < f.spp; s++) {
+            const long long *a = q.accum + 3ull * ((size_t)pm * f.spp + s);
+            sum.x += gclamp(rtFromFixed(a[0]), 0.0f, 1.0f);
+            sum.y += gclamp(rtFromFixed(a[1]), 0.0f, 1.0f);
+            sum.z += gclamp(rtFromFixed(a[2]), 0.0f, 1.0f);
+        }
+        sum = sum / (float)f.spp;
+        const size_t o = ((size_t)(tile0 + (pm >> 8)) * RT_TILE_PIXELS + py * RT_TILE + px) * 3;
+        if (rgbf_tiles) {
+            rgbf_tiles[o] = sum.x;
+            rgbf_tiles[o + 1] = sum.y;
+            rgbf_tiles[o + 2] = sum.z;
+        }
+        if (rgb8_tiles) {
+            rgb8_tiles[o] = (uint8_t)(int)(255 * rtToneMap1(sum.x));
+            rgb8_tiles[o + 1] = (uint8_t)(int)(255 * rtToneMap1(sum.y));
+            rgb8_tiles[o + 2] = (uint8_t)(int)(255 * rtToneMap1(sum.z));
+        }
+    }
+}
+
+// rank-ordered tile-major buffers (what an RCCL gather delivers) -> row-major image
+__global__ __launch_bounds__(RT_BLOCK) void k_assemble(int width, int height, int world, long long tiles_per_rank,
+                                                      const uint8_t *t8, const float *tf, const uint32_t *tp,
+                                                      uint8_t *o8, float *of, uint32_t *op) {
+    const int tiles_x = (width + RT_TILE - 1) / RT_TILE;
+    const size_t npix = (size_t)width * height;
+    for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
+        const int x = (int)(p % width), y = (int)(p / width);
+        const int gt = (y / RT_TILE) * tiles_x + (x / RT_TILE);
+        const int rank = gt % world;
+        const long long lt = gt / world;
+        const size_t src = ((size_t)rank * tiles_per_rank + lt) * RT_TILE_PIXELS + (y % RT_TILE) * RT_TILE + (x % RT_TILE);
+        if (o8 && t8) {
+            o8[3 * p] = t8[3 * src];
+            o8[3 * p + 1] = t8[3 * src + 1];
+            o8[3 * p + 2] = t8[3 * src + 2];
+        }
+        if (of && tf) {
+            of[3 * p] = tf[3 * src];
+            of[3 * p + 1] = tf[3 * src + 1];
+            of[3 * p + 2] = tf[3 * src + 2];
+        }
+        if (op && tp) op[p] = tp[src];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// test hooks
+__global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t root_ref, RtQueues q, uint32_t n,
+                                                     rt_hit *out_hits, uint8_t *out_shadow) {
+    extern __shared__ uint32_t s_stack[];
+    uint32_t *stack = s_stack + threadIdx.x;
+    RtTraversalStats st{0, 0};
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const float4 A = q.rayA[0][i], B = q.rayB[0][i];
+        const float2 hrec = q.hits[i];
+        const uint32_t id = __float_as_uint(hrec.y);
+        const uint32_t sample = __float_as_uint(B.w) & RT_SAMPLE_MASK;
+        RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
+        rt_hit o;
+        memset(&o, 0, sizeof o);
+        o.object = -1;
+        o.triangle = -1;
+        o.prim = RT_PRIM_MISS;
+        o.distance = hrec.x;
+        uint8_t sh[4] = {0, 0, 0, 0};
+        if (id != RT_ID_MISS) {
+            RtFullHit h;
+            rtReconstructHit(sc, r, hrec.x, id, h);
+            o.hit = 1;
+            o.object = h.object;
+            o.prim = h.prim;
+            o.triangle = h.triangle;  // slot; converted to the index inside the mesh on the host
+            o.intersection[0] = h.P.x; o.intersection[1] = h.P.y; o.intersection[2] = h.P.z;
+            o.normal[0] = h.normal.x; o.normal[1] = h.normal.y; o.normal[2] = h.normal.z;
+            o.normal_shading[0] = h.ns.x; o.normal_shading[1] = h.ns.y; o.normal_shading[2] = h.ns.z;
+            o.uv[0] = h.uv.x; o.uv[1] = h.uv.y;
+            o.tangent[0] = h.T.x; o.tangent[1] = h.T.y; o.tangent[2] = h.T.z;
+            o.bitangent[0] = h.B.x; o.bitangent[1] = h.B.y; o.bitangent[2] = h.B.z;
+            if (out_shadow) {
+                const V3 view = normalize(-r.d);
+                V3 normal = h.normal;
+                if (dot(normal, view) < 0) normal = -normal;
+                for (int l = 0; l < sc.n_lights && l < 4; l++) {
+                    const V3 lp = ld3(sc.lights[l].pos);
+                    const V3 ld = normalize(lp - h.P);
+                    const float dl = length(lp - h.P);
+                    bool s = true;
+                    if (!(dot(normal, ld) < 0)) {
+                        RtRay sr{h.P + RT_EPSILON * ld, ld};
+                        s = occluded<false>(sc, root_ref, sr, dl, stack, st);
+                    }
+                    sh[l] = s ? 1 : 0;
+                }
+            }
+        }
+        if (out_hits) out_hits[sample] = o;
+        if (out_shadow)
+            for (int l = 0; l < 4; l++) out_shadow[4 * (size_t)sample + l] = sh[l];
+    }
+}
+
+__global__ void k_rays_from_host(const float *rays, uint32_t n, RtQueues q) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        q.rayA[0][i] = make_float4(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2], 1.0f);
+        q.rayB[0][i] = make_float4(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5], __uint_as_float(i));
+        q.rayR[0][i] = 1.0f;
+        if (i == 0) q.counters[RT_CNT_RAYS0] = n;
+    }
+}
+
+__global__ void k_batch_colors(RtQueues q, uint32_t n, float *out) {  // trace_ray's clamp, main.cpp:232
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int c = 0; c < 3; c++) out[3 * (size_t)i + c] = gclamp(rtFromFixed(q.accum[3 * (size_t)i + c]), 0.0f, 1.0f);
+}
+
+__global__ void k_eval_texture(RtSceneDev sc, int id, long long n, const float *uv, float *out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        V3 c = rtEvalTexture(sc, id, V2{uv[2 * i], uv[2 * i + 1]});
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+    }
+}
+
+__global__ void k_eval_perlin(long long n, const float *p, float *out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = rtPerlin3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers (host).  Grids are sized for the chip (256 CUs), not for the queue: queue lengths live in device memory
+// and the kernels grid-stride over them, so a frame needs no host round trip between levels.
+static inline int gridFor(const RtLaunchCfg &cfg, int blocks_per_cu) { return cfg.num_cus * blocks_per_cu; }
+
+void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles) {
+    hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles);
+}
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    if (stats) hipLaunchKernelGGL(k_closest<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
+    else hipLaunchKernelGGL(k_closest<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
+}
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    if (stats) hipLaunchKernelGGL(k_any<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
+    else hipLaunchKernelGGL(k_any<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
+}
+void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
+                   uint32_t tile0, uint32_t *primid_tiles) {
+    hipLaunchKernelGGL(k_shade, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles);
+}
+void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
+                     uint8_t *rgb8_tiles, float *rgbf_tiles) {
+    hipLaunchKernelGGL(k_resolve, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles, rgb8_tiles, rgbf_tiles);
+}
+void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,
+                      const void *tf, const void *tp, void *o8, void *of, void *op) {
+    hipLaunchKernelGGL(k_assemble, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, width, height, world, tiles_per_rank,
+                       (const uint8_t *)t8, (const float *)tf, (const uint32_t *)tp, (uint8_t *)o8, (float *)of, (uint32_t *)op);
+}
+void rtLaunchHitInfo(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, uint32_t n,
+                     rt_hit *out_hits, uint8_t *out_shadow) {
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_hitinfo, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, n, out_hits, out_shadow);
+}
+void rtLaunchRaysFromHost(const RtLaunchCfg &cfg, const float *d_rays, uint32_t n, const RtQueues &q) {
+    hipLaunchKernelGGL(k_rays_from_host, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), 0, cfg.stream, d_rays, n, q);
+}
+void rtLaunchBatchColors(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t n, float *d_out) {
+    hipLaunchKernelGGL(k_batch_colors, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), 0, cfg.stream, q, n, d_out);
+}
+void rtLaunchEvalTexture(const RtLaunchCfg &cfg, const RtSceneDev &sc, int id, long long n, const float *d_uv, float *d_out) {
+    hipLaunchKernelGGL(k_eval_texture, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), 0, cfg.stream, sc, id, n, d_uv, d_out);
+}
+void rtLaunchEvalPerlin(const RtLaunchCfg &cfg, long long n, const float *d_p, float *d_out) {
+    hipLaunchKernelGGL(k_eval_perlin, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), 0, cfg.stream, n, d_p, d_out);
+}

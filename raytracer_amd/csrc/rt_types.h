@@ -1,0 +1,125 @@
+// rt_types.h -- records shared by the host side of the C ABI (rt_abi.cpp, rt_bvh.cpp) and the HIP kernels.
+// Layouts are fixed-size, 16-byte friendly and documented in DESIGN.md ("data layout in HBM").
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>  // float2 / float4
+#include "../../include/rt_hip.h"
+
+#define RT_TILE 16              // image tile edge, reference main.cpp:565
+#define RT_TILE_PIXELS 256
+#define RT_MAX_LIGHTS 8
+#define RT_MAX_SPHERES 64
+#define RT_MAX_PLANES 64
+#define RT_EPSILON 0.001f       // reference main.cpp:21
+#define RT_ACC_SCALE 4294967296.0   // fixed-point accumulators: 2^32 steps per unit of radiance
+#define RT_ACC_LIMIT 16777216.0f    // contributions are clamped to +-2^24 before conversion
+
+// Linear BVH node, 32 bytes.  Inner: a = index of the left child (the right child is a+1, so a sibling pair is
+// one 64-byte line), b = 0.  Leaf: a = first triangle slot, b = triangle count (1..RT_LEAF_MAX).
+struct RtNode {
+    float mn[3];
+    uint32_t a;
+    float mx[3];
+    uint32_t b;
+};
+#define RT_LEAF_MAX 4
+
+// Triangle as the intersection kernel reads it, 48 bytes, BVH (slot) order:
+// q0 = (A.xyz, n.x)  q1 = (B.xyz, n.y)  q2 = (C.xyz, n.z); n = normalize(cross(B-A, C-A)) (MeshLoader.h:58)
+struct RtTriGeom {
+    float q0[4], q1[4], q2[4];
+};
+
+// Per-slot shading attributes, 80 bytes: what Triangle::intersect needs beyond geometry (MeshLoader.h:99-121)
+struct RtTriShade {
+    float nA[3], nB[3], nC[3];
+    float tA[2], tB[2], tC[2];
+    uint32_t flags;   // bit0 vertexNormals, bit1 vertexTextures
+    int32_t object;   // scene object index
+    uint32_t prim;    // global triangle index (scene order) -- the primitive id reported to the caller
+    uint32_t rank;    // position in the reference's candidate order: resolves exact distance ties like MeshLoader.h:399-404
+    uint32_t _pad;
+};
+
+struct RtSphere {       // Objects.h:12-104
+    float M[16], Minv[16], N[16];
+    int32_t object;
+    int32_t material;
+    int32_t _pad[2];
+};
+
+struct RtPlane {        // Objects.h:109-183
+    float point[3];
+    int32_t object;
+    float normal[3];
+    int32_t material;
+};
+
+struct RtLight {
+    float pos[3];
+    float _p0;
+    float color[3];
+    float _p1;
+};
+
+// Everything a kernel needs to see the scene; passed by value (kernarg -> SGPRs).
+struct RtSceneDev {
+    const RtNode *nodes;
+    const RtTriGeom *tri_geom;
+    const RtTriShade *tri_shade;
+    const RtSphere *spheres;
+    const RtPlane *planes;
+    const rt_material *materials;
+    const int32_t *object_material;
+    const RtLight *lights;
+    const uint8_t *bmp[4];
+    int32_t bmp_w[4], bmp_h[4], bmp_c[4];
+    float ambient[3];
+    int32_t n_nodes, n_tris, n_spheres, n_planes, n_lights, n_objects, n_materials;
+};
+
+// Camera + image constants of the tile loop, precomputed on the host exactly as main.cpp:561-563 does.
+struct RtFrameDev {
+    float origin[3];
+    float dz;
+    float rot[16];
+    float s, X, Y;      // pixel size and image-plane corner
+    int32_t width, height, spp, tiles_x;
+    int32_t tile_rank, tile_world;
+    int32_t use_table;  // 1 = reference jitter table (spp == 4)
+    uint32_t seed;
+};
+
+// hit ids: triangle slot, or analytic primitive
+#define RT_ID_MISS 0xFFFFFFFFu
+#define RT_ID_SPHERE 0x80000000u  // | sphere index
+#define RT_ID_PLANE 0xC0000000u   // | plane index
+#define RT_ID_KIND_MASK 0xC0000000u
+
+// ray flags packed above the sample index (28 bits of sample index)
+#define RT_SAMPLE_MASK 0x0FFFFFFFu
+#define RT_FLAG_HAS_REFR_SIBLING 0x10000000u  // reflection ray whose refraction sibling sits in the next slot
+
+// Wavefront queues of one chunk (device pointers).  Rays: A = (origin.xyz, weight), B = (direction.xyz, sample|flags),
+// R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (origin.xyz, light distance),
+// B = (direction.xyz, sample), C = (pending rgb, 0).
+struct RtQueues {
+    float4 *rayA[2];
+    float4 *rayB[2];
+    float *rayR[2];
+    float2 *hits;
+    float4 *shA, *shB, *shC;
+    long long *accum;          // [chunk samples][3] fixed point
+    uint32_t *counters;        // see RtCounter
+    uint32_t ray_cap, shadow_cap;
+};
+
+enum RtCounter {
+    RT_CNT_RAYS0 = 0,          // rays in queue of level d at RT_CNT_RAYS0 + d (d = 0..15)
+    RT_CNT_SHADOW0 = 16,       // shadow rays of level d
+    RT_CNT_CULLED = 32,
+    RT_CNT_SHADED = 33,
+    RT_CNT_OVERFLOW = 34,
+    RT_CNT_NODES_LO = 36, RT_CNT_NODES_HI = 37, RT_CNT_TRIS_LO = 38, RT_CNT_TRIS_HI = 39,
+    RT_CNT_WORDS = 64
+};
