@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native trace loop.
+
+Workload (BASELINE.json metric, configs[3]): the competition scene (main.cpp:409-536 minus the missing pietre.obj,
+68 202 triangles + 2 planes + 2 spheres, 4 lights) at 3840x2160, 64 spp, bounce depth 3.  One "step" = one frame.
+Scene, BVH and queues are resident in HBM before the timed region; the timed region covers primary-ray generation,
+every trace/shade level, the resolve and (N > 1) the RCCL framebuffer gather + assembly on rank 0.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver with torch.distributed.run (one process per GPU): the frame's 16x16 tiles are
+interleaved over the ranks (tile t -> rank t % N), scene + BVH replicated, one gather at frame end ("strong"
+scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
+
+`roofline` is reported for the dominant kernel (k_closest or k_any, whichever took longer): algorithmic bytes
+(32 B per BVH node fetched + 48 B per triangle tested + 56 B per ray, counted in-kernel) over its summed launch time
+measured with HIP events on the launch stream, against 8 TB/s HBM.  The working set of this scene is cache resident,
+so the fraction is expected to be small; `roofline_valu` prices the same kernel against the FP32 vector peak.
+`cpu_baseline` is the compiled reference (oracle/_ref, `g++ -Ofast -fopenmp`) on a bounded sample of the same scene.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3     # same guide: peak FP32 vector
+
+
+def cpu_baseline(scene_name, sample_w, sample_h):
+    """reference (-Ofast -fopenmp) on a bounded sample of the workload; rays counted by the parity-checked port"""
+    from oracle.binding import Oracle, REF_OFAST
+    from raytracer_amd import FlatScene
+    scene = FlatScene.builtin(scene_name)
+    ref = Oracle(scene).render(sample_w, sample_h, spp=4, max_depth=3)
+    rays = ref["stats"]["rays_closest"] + ref["stats"]["rays_shadow"]
+    port_s = ref["stats"]["ms_total"] / 1e3
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    sample = f"{scene_name} {sample_w}x{sample_h} @4spp depth 3 ({rays} rays)"
+    if os.path.exists(REF_OFAST):
+        out = subprocess.run([REF_OFAST, "render", scene_name, str(sample_w), str(sample_h), "4", "3", "0", "-"],
+                             cwd=os.path.join(REPO, "assets"), capture_output=True, text=True, check=True).stdout
+        info = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        return {"value": rays / info["render_s"] / 1e6, "unit": "Mrays/s", "cores": info["threads"], "kind": "reference",
+                "sample": sample + ", reference built g++ -Ofast -fopenmp", "seconds": info["render_s"],
+                "primary_samples_per_s": sample_w * sample_h * 4 / info["render_s"],
+                "port_mrays_per_s": rays / port_s / 1e6}
+    return {"value": rays / port_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": sample + ", oracle/rt_oracle.cpp -O2 -fopenmp", "seconds": port_s,
+            "primary_samples_per_s": sample_w * sample_h * 4 / port_s}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="competition")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=3)
+    ap.add_argument("--chunk", type=int, default=0, help="primary samples per wavefront chunk (0 = library default)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the two instrumented passes")
+    ap.add_argument("--cpu-sample", default="160x120")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from raytracer_amd import FlatScene
+    from raytracer_amd.renderer import Renderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene = FlatScene.builtin(a.scene)
+    r = Renderer(local_rank).set_scene(scene)
+    W, H = a.width, a.height
+    n_local, n_tiles = r.tile_counts(W, H, rank, world)
+    per = max(r.tile_counts(W, H, k, world)[0] for k in range(world))
+    # tile-major device buffers (torch owns the memory; the renderer writes through raw pointers)
+    t8 = torch.zeros(per, 256, 3, dtype=torch.uint8, device=dev)
+    tp = torch.zeros(per, 256, dtype=torch.int32, device=dev)
+    if rank == 0:
+        g8 = torch.zeros(world, per, 256, 3, dtype=torch.uint8, device=dev)
+        gp = torch.zeros(world, per, 256, dtype=torch.int32, device=dev)
+        o8 = torch.zeros(H, W, 3, dtype=torch.uint8, device=dev)
+        op = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def frame(collect=0):
+        st = r.render_tiles_device(W, H, rank, world, t8.data_ptr(), 0, tp.data_ptr(), stream=stream, spp=a.spp,
+                                   max_depth=a.depth, chunk_samples=a.chunk, collect_stats=collect)
+        if world > 1:  # RCCL gather of the rank-local tile buffers over xGMI, then de-interleave on rank 0
+            dist.gather(t8, list(g8.unbind(0)) if rank == 0 else None, dst=0)
+            dist.gather(tp, list(gp.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                r.assemble_tiles_device(W, H, world, per, g8.data_ptr(), 0, gp.data_ptr(), o8.data_ptr(), 0, op.data_ptr(), stream=stream)
+        elif rank == 0:
+            r.assemble_tiles_device(W, H, 1, per, t8.data_ptr(), 0, tp.data_ptr(), o8.data_ptr(), 0, op.data_ptr(), stream=stream)
+        return st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        frame()
+    sync()
+    t0 = time.perf_counter()
+    rays = 0
+    prim = 0
+    for _ in range(a.steps):
+        st = frame()
+        rays += st["rays_closest"] + st["rays_shadow"]
+        prim += st["primary_samples"]
+    sync()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([dt, float(rays), float(prim)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+    rays_all, prim_all = float(tot[1]), float(tot[2])
+
+    result = None
+    if rank == 0:
+        result = {
+            "metric": "Mrays/s", "value": rays_all / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / max(a.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "reference scene assets (meshes/*.obj), synthetic camera samples",
+            "config": {"workload": f"{a.scene} scene {W}x{H} @{a.spp}spp depth {a.depth}", "triangles": scene.n_triangles,
+                       "tiles": n_tiles, "parallelism": f"tiles%{world}", "chunk_samples": a.chunk or (1 << 21)},
+            "primary_samples_per_s": prim_all / dt, "rays_per_primary": rays_all / max(prim_all, 1.0),
+            "ms_per_frame": dt / max(a.steps, 1) * 1e3,
+        }
+    if rank == 0 and not a.no_roofline:
+        timed = frame(collect=2)       # per-kernel-class HIP-event timing on the launch stream
+        counted = frame(collect=1)     # in-kernel node / triangle counters (slower kernels, counts only)
+        launches = max(timed["launches_closest"], 1)
+        kinds = {
+            "k_closest": (timed["ms_closest"], counted["nodes_visited"], counted["tris_tested"], counted["rays_closest"]),
+            "k_any": (timed["ms_any"], counted["nodes_visited_any"], counted["tris_tested_any"], counted["rays_shadow"]),
+        }
+        name = max(kinds, key=lambda k: kinds[k][0])
+        ms, nodes, tris, nrays = kinds[name]
+        abytes = 32.0 * nodes + 48.0 * tris + 56.0 * nrays
+        flops = 20.0 * nodes + 80.0 * tris
+        ach = abytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+        result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                              "bytes_per_launch": abytes / launches, "avg_launch_ms": ms / launches, "launches": launches,
+                              "nodes_per_ray": nodes / max(nrays, 1), "tris_per_ray": tris / max(nrays, 1)}
+        tf = flops / (ms / 1e3) / 1e12 if ms > 0 else 0.0
+        result["roofline_valu"] = {"kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
+                                   "note": "20 flop per slab test + 80 per triangle test (SURVEY.md 8(d))"}
+        result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
+    if rank == 0 and not a.no_cpu and world == 1:
+        try:
+            sw, sh = (int(x) for x in a.cpu_sample.split("x"))
+            result["cpu_baseline"] = cpu_baseline(a.scene, sw, sh)
+        except Exception as e:  # the baseline is a reported number, not a dependency of the measurement
+            result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,7 +88,8 @@ typedef struct rt_render_params {
     int32_t tile_rank;      /* this context renders tiles t with t % tile_world == tile_rank (16x16 tiles, main.cpp:565) */
     int32_t tile_world;     /* 1 = whole image */
     int64_t chunk_samples;  /* primary samples per wavefront chunk; 0 = default */
-    int32_t collect_stats;  /* 1 = count BVH nodes / triangle tests in-kernel (slower) */
+    int32_t collect_stats;  /* bit0: count BVH node fetches / triangle tests in-kernel (slower);
+                               bit1: time every kernel class with HIP events on the launch stream (ms_gen ...) */
     int32_t _pad;
 } rt_render_params;
 
@@ -98,13 +99,15 @@ typedef struct rt_stats {
     uint64_t rays_shadow;     /* shadow rays traced (Ray ctor at main.cpp:49; back-face culled ones are not rays) */
     uint64_t shadow_culled;   /* lights rejected by main.cpp:44-46 */
     uint64_t hits_shaded;     /* PhongModel invocations */
-    uint64_t nodes_visited;   /* BVH nodes fetched   (collect_stats only) */
-    uint64_t tris_tested;     /* triangle tests      (collect_stats only) */
+    uint64_t nodes_visited;   /* BVH nodes fetched by closest-hit rays  (collect_stats & 1 only) */
+    uint64_t tris_tested;     /* triangle tests of closest-hit rays     (collect_stats & 1 only) */
     uint64_t queue_overflow;  /* must be 0 */
     double ms_total;          /* GPU time of the whole call (HIP events) */
     double ms_gen, ms_closest, ms_shade, ms_any, ms_resolve; /* per kernel class, summed over launches */
     uint64_t launches_closest, launches_any;
     uint64_t bvh_nodes, bvh_depth, n_triangles;
+    uint64_t nodes_visited_any; /* BVH nodes fetched by shadow rays (collect_stats & 1 only) */
+    uint64_t tris_tested_any;   /* triangle tests of shadow rays    (collect_stats & 1 only) */
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

@@ -184,6 +184,8 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
     st->queue_overflow += c[RT_CNT_OVERFLOW];
     st->nodes_visited += ((uint64_t)c[RT_CNT_NODES_HI] << 32) | c[RT_CNT_NODES_LO];
     st->tris_tested += ((uint64_t)c[RT_CNT_TRIS_HI] << 32) | c[RT_CNT_TRIS_LO];
+    st->nodes_visited_any += ((uint64_t)c[RT_CNT_ANY_NODES_HI] << 32) | c[RT_CNT_ANY_NODES_LO];
+    st->tris_tested_any += ((uint64_t)c[RT_CNT_ANY_TRIS_HI] << 32) | c[RT_CNT_ANY_TRIS_LO];
 }
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled

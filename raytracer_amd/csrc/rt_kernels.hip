@@ -175,15 +175,15 @@ RT_DEV bool occluded(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, fl
     return traverseBvh<true, STATS>(sc, root_ref, r, tmax, id, stack, st);
 }
 
-RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st) {
+RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st, int nodes_word) {
     unsigned long long n = st.nodes, t = st.tris;
     for (int off = 32; off > 0; off >>= 1) {
         n += __shfl_down(n, off);
         t += __shfl_down(t, off);
     }
     if (laneId() == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long *>(counters + RT_CNT_NODES_LO), n);
-        atomicAdd(reinterpret_cast<unsigned long long *>(counters + RT_CNT_TRIS_LO), t);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + nodes_word), n);
+        atomicAdd(reinterpret_cast<unsigned long long *>(counters + nodes_word + 2), t);
     }
 }
 
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t ro
         closestHit<STATS>(sc, root_ref, r, t, id, stack, st);
         q.hits[i] = make_float2(t, __uint_as_float(id));
     }
-    if (STATS) flushStats(q.counters, st);
+    if (STATS) flushStats(q.counters, st, RT_CNT_NODES_LO);
 }
 
 template <bool STATS>
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_r
             atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
         }
     }
-    if (STATS) flushStats(q.counters, st);
+    if (STATS) flushStats(q.counters, st, RT_CNT_ANY_NODES_LO);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -120,6 +120,7 @@ enum RtCounter {
     RT_CNT_CULLED = 32,
     RT_CNT_SHADED = 33,
     RT_CNT_OVERFLOW = 34,
-    RT_CNT_NODES_LO = 36, RT_CNT_NODES_HI = 37, RT_CNT_TRIS_LO = 38, RT_CNT_TRIS_HI = 39,
+    RT_CNT_NODES_LO = 36, RT_CNT_NODES_HI = 37, RT_CNT_TRIS_LO = 38, RT_CNT_TRIS_HI = 39,   // closest-hit rays
+    RT_CNT_ANY_NODES_LO = 40, RT_CNT_ANY_NODES_HI = 41, RT_CNT_ANY_TRIS_LO = 42, RT_CNT_ANY_TRIS_HI = 43,  // shadow rays
     RT_CNT_WORDS = 64
 };
