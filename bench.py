@@ -150,7 +150,7 @@ def main():
             "config": {"workload": f"{a.scene} scene {W}x{H} @{a.spp}spp depth {a.depth}", "triangles": scene.n_triangles,
                        "tiles": n_tiles, "parallelism": f"tiles%{world}", "chunk_samples": a.chunk or (1 << 21)},
             "primary_samples_per_s": prim_all / dt, "rays_per_primary": rays_all / max(prim_all, 1.0),
-            "ms_per_frame": dt / max(a.steps, 1) * 1e3,
+            "ms_per_frame": dt / max(a.steps, 1) * 1e3, "bvh": {"nodes": st["bvh_nodes"], "depth": st["bvh_depth"]},
         }
     if rank == 0 and not a.no_roofline:
         timed = frame(collect=2)       # per-kernel-class HIP-event timing on the launch stream

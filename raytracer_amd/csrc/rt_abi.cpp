@@ -176,16 +176,18 @@ struct KernelTimer {  // optional per-kernel-class timing with HIP events on the
 
 void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
     for (int d = 0; d <= max_depth && d < 16; d++) {
-        st->rays_closest += c[RT_CNT_RAYS0 + d];
-        st->rays_shadow += c[RT_CNT_SHADOW0 + d];
+        st->rays_closest += c[RT_CNT_RAYS(d)];
+        st->rays_shadow += c[RT_CNT_SHADOW(d)];
     }
+    st->rays_closest -= c[RT_CNT_INVALID];  // level-0 slots of pixels outside the image are not rays
     st->shadow_culled += c[RT_CNT_CULLED];
     st->hits_shaded += c[RT_CNT_SHADED];
     st->queue_overflow += c[RT_CNT_OVERFLOW];
-    st->nodes_visited += ((uint64_t)c[RT_CNT_NODES_HI] << 32) | c[RT_CNT_NODES_LO];
-    st->tris_tested += ((uint64_t)c[RT_CNT_TRIS_HI] << 32) | c[RT_CNT_TRIS_LO];
-    st->nodes_visited_any += ((uint64_t)c[RT_CNT_ANY_NODES_HI] << 32) | c[RT_CNT_ANY_NODES_LO];
-    st->tris_tested_any += ((uint64_t)c[RT_CNT_ANY_TRIS_HI] << 32) | c[RT_CNT_ANY_TRIS_LO];
+    auto u64at = [&](int w) { return ((uint64_t)c[w + 1] << 32) | c[w]; };
+    st->nodes_visited += u64at(RT_CNT_NODES);
+    st->tris_tested += u64at(RT_CNT_NODES + 2);
+    st->nodes_visited_any += u64at(RT_CNT_ANY_NODES);
+    st->tris_tested_any += u64at(RT_CNT_ANY_NODES + 2);
 }
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
@@ -406,7 +408,13 @@ int rt_set_spheres(rt_context *ctx, int32_t n, const float *M, const float *Minv
         std::memcpy(s.N, Nmat + 16 * k, 64);
         s.object = object_id[k];
         s.material = 0;
-        s._pad[0] = s._pad[1] = 0;
+        for (int a = 0; a < 3; a++) {  // extent of M * unit ball along axis a = |row a of the linear part|
+            const double r = std::sqrt((double)s.M[a] * s.M[a] + (double)s.M[4 + a] * s.M[4 + a] + (double)s.M[8 + a] * s.M[8 + a]);
+            const double c = s.M[12 + a], pad = 1e-3 * r + 1e-5 * std::fabs(c) + 1e-30;
+            s.box_mn[a] = (float)(c - r - pad);
+            s.box_mx[a] = (float)(c + r + pad);
+        }
+        std::memset(s._pad, 0, sizeof s._pad);
     }
     ctx->committed = false;
     return 0;
@@ -538,7 +546,8 @@ int rt_commit(rt_context *ctx) {
     while (entries < ctx->bvh.depth + 1) entries += 8;
     if (entries > 160) return fail("rt_commit: BVH deeper than the LDS stack budget");
     ctx->cfg.stack_entries = entries;
-    const int lds_per_block = entries * 256 * 4;
+    ctx->cfg.analytic_bytes = (int)(ctx->spheres.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
+    const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
     ctx->committed = true;
     return 0;

@@ -9,7 +9,8 @@
 //   k_assemble      tile-major rank buffers -> row-major image (multi-GPU gather epilogue)
 //   k_hitinfo / k_eval_texture / k_eval_perlin   test hooks of the C ABI
 //
-// Queues are compacted with 64-wide ballots: one atomic per wave reserves a block, mbcnt gives the lane offset.
+// Queues are compacted with 64-wide ballots (mbcnt gives the lane offset inside the wave) and reserved with ONE atomic
+// per 256-thread block and queue.
 // Traversal keeps a per-lane stack in LDS, laid out [entry][lane] so that a wave's push/pop is conflict-free.
 #include <hip/hip_runtime.h>
 #include "rt_device.h"
@@ -63,11 +64,9 @@ RT_DEV float safeInv(float d) {
 // ANY = false: closest hit with the reference's tie rule; ANY = true: first hit with t <= tmax ends the walk.
 // `stack` points at this lane's column of the block's LDS stack (stride RT_BLOCK words).
 template <bool ANY, bool STATS>
-RT_DEV bool traverseBvh(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, float &best_t, uint32_t &best_id,
-                        uint32_t *stack, RtTraversalStats &st) {
+RT_DEV bool traverseBvh(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, V3 inv, V3 oi, float &best_t,
+                        uint32_t &best_id, uint32_t *stack, RtTraversalStats &st) {
     if (sc.n_tris == 0) return false;
-    const V3 inv = v3(safeInv(r.d.x), safeInv(r.d.y), safeInv(r.d.z));
-    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
     const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
     uint32_t cur = root_ref;
     int sp = 0;
@@ -131,48 +130,79 @@ RT_DEV bool traverseBvh(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r,
     return found;
 }
 
+// Analytic primitives are staged once per block into LDS (a few hundred bytes; every lane of every ray reads all of
+// them, so they are the hottest scene data) behind the traversal stack: [stack][spheres][planes].
+struct RtAnalytic {
+    const RtSphere *spheres;
+    const RtPlane *planes;
+};
+RT_DEV RtAnalytic stageAnalytic(const RtSceneDev &sc, uint32_t *lds_after_stack) {
+    uint32_t *dst = lds_after_stack;
+    const uint32_t nsw = (uint32_t)sc.n_spheres * (sizeof(RtSphere) / 4), npw = (uint32_t)sc.n_planes * (sizeof(RtPlane) / 4);
+    const uint32_t *ss = reinterpret_cast<const uint32_t *>(sc.spheres), *ps = reinterpret_cast<const uint32_t *>(sc.planes);
+    for (uint32_t k = threadIdx.x; k < nsw; k += blockDim.x) dst[k] = ss[k];
+    for (uint32_t k = threadIdx.x; k < npw; k += blockDim.x) dst[nsw + k] = ps[k];
+    __syncthreads();
+    return RtAnalytic{reinterpret_cast<const RtSphere *>(dst), reinterpret_cast<const RtPlane *>(dst + nsw)};
+}
+RT_DEV bool sphereBoxHit(const RtSphere &sp, V3 inv, V3 oi) {
+    float tn;
+    return slabHit(make_float4(sp.box_mn[0], sp.box_mn[1], sp.box_mn[2], 0.0f), make_float4(sp.box_mx[0], sp.box_mx[1], sp.box_mx[2], 0.0f),
+                   inv, oi, INFINITY, tn);
+}
+
 // closest(): analytic primitives in scene order, then the triangle BVH (ties resolved by object order above)
 template <bool STATS>
-RT_DEV void closestHit(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, float &best_t, uint32_t &best_id,
-                       uint32_t *stack, RtTraversalStats &st) {
+RT_DEV void closestHit(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtRay &r, float &best_t,
+                       uint32_t &best_id, uint32_t *stack, RtTraversalStats &st) {
     best_t = INFINITY;
     best_id = RT_ID_MISS;
     int best_obj = 0x7FFFFFFF;
+    const V3 inv = v3(safeInv(r.d.x), safeInv(r.d.y), safeInv(r.d.z));
+    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
     for (int k = 0; k < sc.n_spheres; k++) {
+        const RtSphere &sp = an.spheres[k];
+        if (!sphereBoxHit(sp, inv, oi)) continue;
         float dist;
         V3 ni, P;
-        if (rtSphereHit(sc.spheres[k], r, dist, ni, P) && (dist < best_t || (dist == best_t && sc.spheres[k].object < best_obj))) {
+        if (rtSphereHit(sp, r, dist, ni, P) && (dist < best_t || (dist == best_t && sp.object < best_obj))) {
             best_t = dist;
             best_id = RT_ID_SPHERE | (uint32_t)k;
-            best_obj = sc.spheres[k].object;
+            best_obj = sp.object;
         }
     }
     for (int k = 0; k < sc.n_planes; k++) {
+        const RtPlane &pl = an.planes[k];
         float t;
-        if (rtPlaneHit(sc.planes[k], r, t) && (t < best_t || (t == best_t && sc.planes[k].object < best_obj))) {
+        if (rtPlaneHit(pl, r, t) && (t < best_t || (t == best_t && pl.object < best_obj))) {
             best_t = t;
             best_id = RT_ID_PLANE | (uint32_t)k;
-            best_obj = sc.planes[k].object;
+            best_obj = pl.object;
         }
     }
-    traverseBvh<false, STATS>(sc, root_ref, r, best_t, best_id, stack, st);
+    traverseBvh<false, STATS>(sc, root_ref, r, inv, oi, best_t, best_id, stack, st);
 }
 
 // is_shadowed() after its back-face test: any object with hit.distance <= dist (main.cpp:50-55)
 template <bool STATS>
-RT_DEV bool occluded(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, float dist, uint32_t *stack, RtTraversalStats &st) {
-    for (int k = 0; k < sc.n_spheres; k++) {
-        float d;
-        V3 ni, P;
-        if (rtSphereHit(sc.spheres[k], r, d, ni, P) && d <= dist) return true;
-    }
+RT_DEV bool occluded(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtRay &r, float dist,
+                     uint32_t *stack, RtTraversalStats &st) {
+    const V3 inv = v3(safeInv(r.d.x), safeInv(r.d.y), safeInv(r.d.z));
+    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
     for (int k = 0; k < sc.n_planes; k++) {
         float t;
-        if (rtPlaneHit(sc.planes[k], r, t) && t <= dist) return true;
+        if (rtPlaneHit(an.planes[k], r, t) && t <= dist) return true;
+    }
+    for (int k = 0; k < sc.n_spheres; k++) {
+        const RtSphere &sp = an.spheres[k];
+        if (!sphereBoxHit(sp, inv, oi)) continue;
+        float d;
+        V3 ni, P;
+        if (rtSphereHit(sp, r, d, ni, P) && d <= dist) return true;
     }
     float tmax = dist;
     uint32_t id = RT_ID_MISS;
-    return traverseBvh<true, STATS>(sc, root_ref, r, tmax, id, stack, st);
+    return traverseBvh<true, STATS>(sc, root_ref, r, inv, oi, tmax, id, stack, st);
 }
 
 RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st, int nodes_word) {
@@ -199,79 +229,79 @@ RT_DEV uint32_t compact1By1(uint32_t x) {
     return x;
 }
 
+// Level 0 needs no compaction: slot == sample index inside the chunk.  Slots of pixels outside the image (ragged
+// edge tiles) are flagged invalid; k_closest records a miss for them and k_shade ignores them.
 __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues q, uint32_t tile0, uint32_t ntiles) {
     const uint32_t total = ntiles * RT_TILE_PIXELS * (uint32_t)f.spp;
-    const uint32_t rounded = (total + 63u) & ~63u;
-    for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < rounded; idx += gridDim.x * RT_BLOCK) {
-        bool valid = idx < total;
-        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, 0);
-        if (valid) {
-            const uint32_t s = idx % (uint32_t)f.spp, pm = idx / (uint32_t)f.spp;
-            const uint32_t m = pm & 255u, lt = tile0 + (pm >> 8);
-            const uint32_t gt = lt * (uint32_t)f.tile_world + (uint32_t)f.tile_rank;
-            const int i = (int)((gt % (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m));
-            const int j = (int)((gt / (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m >> 1));
-            valid = i < f.width && j < f.height;
-            if (valid) {
-                float jx, jy;
-                if (f.use_table) {  // jitterMatrix, main.cpp:601-606 (selects, not an indexed array: no scratch)
-                    const uint32_t k = s & 3u;
-                    jx = k == 0 ? (float)(-1.0 / 4.0) : (k == 1 ? (float)(3.0 / 4.0) : (k == 2 ? (float)(-3.0 / 4.0) : (float)(1.0 / 4.0)));
-                    jy = k == 0 ? (float)(3.0 / 4.0) : (k == 1 ? (float)(1.0 / 3.0) : (k == 2 ? (float)(-1.0 / 4.0) : (float)(-3.0 / 4.0)));
-                } else {
-                    rtHashJitter((uint32_t)(j * f.width + i), s, f.seed, jx, jy);
-                }
-                const float dx = f.X + ((float)i + jx) * f.s + f.s / 2;  // main.cpp:629-630
-                const float dy = f.Y - ((float)j + jy) * f.s - f.s / 2;
-                const V3 d = normalize(mulPoint(f.rot, v3(dx, dy, f.dz), 0.0f));  // :637-641
-                A = make_float4(f.origin[0], f.origin[1], f.origin[2], 1.0f);
-                B = make_float4(d.x, d.y, d.z, __uint_as_float(idx));
-            }
-        }
-        const unsigned long long mask = __ballot(valid);
-        const uint32_t base = waveReserve(q.counters + RT_CNT_RAYS0, (uint32_t)__popcll(mask));
-        if (valid) {
-            const uint32_t slot = base + maskRankBelow(mask);
-            if (slot < q.ray_cap) {
-                q.rayA[0][slot] = A;
-                q.rayB[0][slot] = B;
-                q.rayR[0][slot] = 1.0f;
+    uint32_t invalid = 0;
+    for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * RT_BLOCK) {
+        const uint32_t s = idx % (uint32_t)f.spp, pm = idx / (uint32_t)f.spp;
+        const uint32_t m = pm & 255u, lt = tile0 + (pm >> 8);
+        const uint32_t gt = lt * (uint32_t)f.tile_world + (uint32_t)f.tile_rank;
+        const int i = (int)((gt % (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m));
+        const int j = (int)((gt / (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m >> 1));
+        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 1, __uint_as_float(idx | RT_FLAG_INVALID));
+        if (i < f.width && j < f.height) {
+            float jx, jy;
+            if (f.use_table) {  // jitterMatrix, main.cpp:601-606 (selects, not an indexed array: no scratch)
+                const uint32_t k = s & 3u;
+                jx = k == 0 ? (float)(-1.0 / 4.0) : (k == 1 ? (float)(3.0 / 4.0) : (k == 2 ? (float)(-3.0 / 4.0) : (float)(1.0 / 4.0)));
+                jy = k == 0 ? (float)(3.0 / 4.0) : (k == 1 ? (float)(1.0 / 3.0) : (k == 2 ? (float)(-1.0 / 4.0) : (float)(-3.0 / 4.0)));
             } else {
-                atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+                rtHashJitter((uint32_t)(j * f.width + i), s, f.seed, jx, jy);
             }
+            const float dx = f.X + ((float)i + jx) * f.s + f.s / 2;  // main.cpp:629-630
+            const float dy = f.Y - ((float)j + jy) * f.s - f.s / 2;
+            const V3 d = normalize(mulPoint(f.rot, v3(dx, dy, f.dz), 0.0f));  // :637-641
+            A = make_float4(f.origin[0], f.origin[1], f.origin[2], 1.0f);
+            B = make_float4(d.x, d.y, d.z, __uint_as_float(idx));
+        } else {
+            invalid++;
         }
+        q.rayA[0][idx] = A;
+        q.rayB[0][idx] = B;
+        q.rayR[0][idx] = 1.0f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) q.counters[RT_CNT_RAYS(0)] = min(total, q.ray_cap);
+    if (__ballot(invalid != 0)) {
+        for (int off = 32; off > 0; off >>= 1) invalid += __shfl_down(invalid, off);
+        if (laneId() == 0 && invalid) atomicAdd(q.counters + RT_CNT_INVALID, invalid);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level) {
-    extern __shared__ uint32_t s_stack[];
-    uint32_t *stack = s_stack + threadIdx.x;
+__global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+    extern __shared__ uint32_t s_lds[];
+    uint32_t *stack = s_lds + threadIdx.x;
+    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
     const int buf = level & 1;
-    const uint32_t n = min(q.counters[RT_CNT_RAYS0 + level], q.ray_cap);
+    const uint32_t n = min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
     RtTraversalStats st{0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 A = q.rayA[buf][i], B = q.rayB[buf][i];
-        RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
-        float t;
-        uint32_t id;
-        closestHit<STATS>(sc, root_ref, r, t, id, stack, st);
+        float t = INFINITY;
+        uint32_t id = RT_ID_MISS;
+        if (!(__float_as_uint(B.w) & RT_FLAG_INVALID)) {
+            RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
+            closestHit<STATS>(sc, an, root_ref, r, t, id, stack, st);
+        }
         q.hits[i] = make_float2(t, __uint_as_float(id));
     }
-    if (STATS) flushStats(q.counters, st, RT_CNT_NODES_LO);
+    if (STATS) flushStats(q.counters, st, RT_CNT_NODES);
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level) {
-    extern __shared__ uint32_t s_stack[];
-    uint32_t *stack = s_stack + threadIdx.x;
-    const uint32_t n = min(q.counters[RT_CNT_SHADOW0 + level], q.shadow_cap);
+__global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+    extern __shared__ uint32_t s_lds[];
+    uint32_t *stack = s_lds + threadIdx.x;
+    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
+    const uint32_t n = min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap);
     RtTraversalStats st{0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 A = q.shA[i], B = q.shB[i];
         RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
-        if (!occluded<STATS>(sc, root_ref, r, A.w, stack, st)) {
+        if (!occluded<STATS>(sc, an, root_ref, r, A.w, stack, st)) {
             const float4 C = q.shC[i];
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * __float_as_uint(B.w);
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
@@ -279,7 +309,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_r
             atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
         }
     }
-    if (STATS) flushStats(q.counters, st, RT_CNT_ANY_NODES_LO);
+    if (STATS) flushStats(q.counters, st, RT_CNT_ANY_NODES);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -288,15 +318,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_r
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles) {
+    // queue reservation is aggregated per BLOCK: waves post their counts in LDS, one lane per queue does the global
+    // atomic (a returning atomic on one address retires every ~10 ns chip-wide, so per-wave reservations of ~40 M
+    // waves per frame would serialise), everybody derives its slot from the block base.  Double-buffered by loop
+    // parity so that one barrier pair per iteration suffices.
+    __shared__ uint32_t s_cnt[2][2][RT_BLOCK / 64];
+    __shared__ uint32_t s_base[2][2];
     const int buf = level & 1, nbuf = buf ^ 1;
-    const uint32_t n = min(q.counters[RT_CNT_RAYS0 + level], q.ray_cap);
-    const uint32_t rounded = (n + 63u) & ~63u;
+    const uint32_t n = min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    const uint32_t rounded = (n + (RT_BLOCK - 1)) & ~(uint32_t)(RT_BLOCK - 1);  // uniform trip count per block
     const int remaining = max_depth - level;
+    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    const int nlights = sc.n_lights;
     uint32_t culled = 0, shaded = 0;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < rounded; i += gridDim.x * RT_BLOCK) {
+    int parity = 0;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < rounded; i += gridDim.x * RT_BLOCK, parity ^= 1) {
         bool active = i < n;
         float2 hrec = make_float2(0.0f, __uint_as_float(RT_ID_MISS));
-        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, 0);
+        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_INVALID));
         if (active) {
             hrec = q.hits[i];
             A = q.rayA[buf][i];
@@ -304,7 +343,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, i
         }
         const uint32_t id = __float_as_uint(hrec.y);
         const uint32_t sflags = __float_as_uint(B.w), sample = sflags & RT_SAMPLE_MASK;
-        if (active && level == 0 && primid_tiles && (sample % (uint32_t)spp) == 0) {
+        if (active && level == 0 && primid_tiles && !(sflags & RT_FLAG_INVALID) && (sample % (uint32_t)spp) == 0) {
             // primitive hit by sample 0 of the pixel, written tile-major at y*16+x
             const uint32_t pm = sample / (uint32_t)spp, m = pm & 255u;
             const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
@@ -319,7 +358,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, i
         }
         active = active && id != RT_ID_MISS;
 
-        // per-lane state carried from the shading step to the (wave-uniform) emission steps
+        // per-lane state carried from the shading step to the (block-uniform) emission steps
         V3 P = v3s(0), ns = v3s(0), view = v3s(0), normal = v3s(0), dcol = v3s(0), mspec = v3s(0), hT = v3s(0), hB = v3s(0);
         float weight = 0.0f, shiny = 0.0f, alpha_x = 1.0f, alpha_y = 1.0f, directScale = 1.0f, directScale2 = 1.0f;
         bool aniso = false;
@@ -327,7 +366,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, i
         bool emitRefl = false, emitRefr = false;
         V3 reflDir = v3s(0), refrDir = v3s(0);
         float wRefl = 0, wRefr = 0, fresnelR = 1.0f;
-        const int nlights = sc.n_lights;
 
         if (active) {
             shaded++;
@@ -405,68 +443,76 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, i
             }
         }
 
-        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  Lights are
-        // processed four at a time; emission is wave-compacted and light-major inside the wave so that a batch of
-        // shadow rays towards one light stays coherent for k_any.
-        for (int l0 = 0; l0 < nlights; l0 += 4) {
-            unsigned long long masks[4];
-            uint32_t total = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                masks[k] = __ballot((litmask >> (l0 + k)) & 1u);
-                total += (uint32_t)__popcll(masks[k]);
-            }
-            const uint32_t base = waveReserve(q.counters + RT_CNT_SHADOW0 + level, total);
-            uint32_t off = base;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int l = l0 + k;
-                if ((litmask >> l) & 1u) {
-                    const V3 lp = ld3(sc.lights[l].pos), lc = ld3(sc.lights[l].color);
-                    const V3 ld = normalize(lp - P);                     // main.cpp:97
-                    const float dl = length(lp - P);                     // :98
-                    const float diffuse = smax(0.0f, dot(ld, ns));       // :104
-                    const V3 hv = normalize(ld + view);                  // :106
-                    const float distance = smax(0.1f, dl);               // :109
-                    const float attenuation = (float)(1.0 / ((double)distance * (double)distance));  // :110 (double pow)
-                    const V3 diffusion = attenuation * lc * dcol * diffuse;
-                    V3 spec = v3s(0.0f);
-                    if (aniso) {  // main.cpp:123-139
-                        const float NdotL = dot(ns, ld), NdotV = dot(ns, view);
-                        if (NdotL > 0 && NdotV > 0) {
-                            const float HdotT = dot(hv, hT), HdotB = dot(hv, hB), HdotN = dot(hv, ns);
-                            const float e1 = HdotT / alpha_x, e2 = HdotB / alpha_y;
-                            const float exponent = -2.0f * (powf(e1, 2.0f) * powf(e2, 2.0f)) / (1 + HdotN);
-                            const float pi = 3.14159265358979323846264338327950288f;
-                            spec = (mspec * NdotL * expf(exponent)) / (sqrtf(NdotL * NdotV) * 4 * pi * alpha_x * alpha_y);
-                        }
-                    } else {  // :141-142; std::max(0.0f, NaN) == 0.0f
-                        const float specular = smax(0.0f, powf(dot(hv, ns), 4 * shiny));
-                        spec = attenuation * lc * mspec * specular;
+        // ---- block-aggregated reservation of shadow-ray and next-level slots ----
+        uint32_t totS = 0;
+        for (int l = 0; l < nlights; l++) totS += (uint32_t)__popcll(__ballot((litmask >> l) & 1u));
+        const unsigned long long mRefl = __ballot(emitRefl), mRefr = __ballot(emitRefr);
+        const uint32_t totR = (uint32_t)(__popcll(mRefl) + __popcll(mRefr));
+        if (lane == 0) {
+            s_cnt[parity][0][wave] = totS;
+            s_cnt[parity][1][wave] = totR;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            uint32_t sum = 0;
+            for (int w = 0; w < RT_BLOCK / 64; w++) sum += s_cnt[parity][threadIdx.x][w];
+            uint32_t *ctr = q.counters + (threadIdx.x == 0 ? RT_CNT_SHADOW(level) : RT_CNT_RAYS(level + 1));
+            s_base[parity][threadIdx.x] = sum ? atomicAdd(ctr, sum) : 0u;
+        }
+        __syncthreads();
+        uint32_t offS = s_base[parity][0], offR = s_base[parity][1];
+        for (uint32_t w = 0; w < wave; w++) {
+            offS += s_cnt[parity][0][w];
+            offR += s_cnt[parity][1][w];
+        }
+
+        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  Inside the
+        // wave's slab the rays are light-major, so a batch of shadow rays towards one light stays coherent for k_any.
+        for (int l = 0; l < nlights; l++) {
+            const bool lit = (litmask >> l) & 1u;
+            const unsigned long long mask = __ballot(lit);
+            if (lit) {
+                const V3 lp = ld3(sc.lights[l].pos), lc = ld3(sc.lights[l].color);
+                const V3 ld = normalize(lp - P);                     // main.cpp:97
+                const float dl = length(lp - P);                     // :98
+                const float diffuse = smax(0.0f, dot(ld, ns));       // :104
+                const V3 hv = normalize(ld + view);                  // :106
+                const float distance = smax(0.1f, dl);               // :109
+                const float attenuation = (float)(1.0 / ((double)distance * (double)distance));  // :110 (double pow)
+                const V3 diffusion = attenuation * lc * dcol * diffuse;
+                V3 spec = v3s(0.0f);
+                if (aniso) {  // main.cpp:123-139
+                    const float NdotL = dot(ns, ld), NdotV = dot(ns, view);
+                    if (NdotL > 0 && NdotV > 0) {
+                        const float HdotT = dot(hv, hT), HdotB = dot(hv, hB), HdotN = dot(hv, ns);
+                        const float e1 = HdotT / alpha_x, e2 = HdotB / alpha_y;
+                        const float exponent = -2.0f * (powf(e1, 2.0f) * powf(e2, 2.0f)) / (1 + HdotN);
+                        const float pi = 3.14159265358979323846264338327950288f;
+                        spec = (mspec * NdotL * expf(exponent)) / (sqrtf(NdotL * NdotV) * 4 * pi * alpha_x * alpha_y);
                     }
-                    V3 c = diffusion + spec;
-                    c = c * directScale;   // x * 1.0f is exact when no scaling applies
-                    c = c * directScale2;
-                    c = c * weight;
-                    const uint32_t slot = off + maskRankBelow(masks[k]);
-                    if (slot < q.shadow_cap) {
-                        const V3 so = P + RT_EPSILON * ld;  // main.cpp:49
-                        q.shA[slot] = make_float4(so.x, so.y, so.z, dl);
-                        q.shB[slot] = make_float4(ld.x, ld.y, ld.z, __uint_as_float(sample));
-                        q.shC[slot] = make_float4(c.x, c.y, c.z, 0.0f);
-                    } else {
-                        atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
-                    }
+                } else {  // :141-142; std::max(0.0f, NaN) == 0.0f
+                    const float specular = smax(0.0f, powf(dot(hv, ns), 4 * shiny));
+                    spec = attenuation * lc * mspec * specular;
                 }
-                off += (uint32_t)__popcll(masks[k]);
+                V3 c = diffusion + spec;
+                c = c * directScale;   // x * 1.0f is exact when no scaling applies
+                c = c * directScale2;
+                c = c * weight;
+                const uint32_t slot = offS + maskRankBelow(mask);
+                if (slot < q.shadow_cap) {
+                    const V3 so = P + RT_EPSILON * ld;  // main.cpp:49
+                    q.shA[slot] = make_float4(so.x, so.y, so.z, dl);
+                    q.shB[slot] = make_float4(ld.x, ld.y, ld.z, __uint_as_float(sample));
+                    q.shC[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+                } else {
+                    atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+                }
             }
+            offS += (uint32_t)__popcll(mask);
         }
         // ---- next-level rays, lane-major so that a reflection/refraction pair stays adjacent ----
         {
-            const unsigned long long mRefl = __ballot(emitRefl), mRefr = __ballot(emitRefr);
-            const uint32_t total = (uint32_t)(__popcll(mRefl) + __popcll(mRefr));
-            const uint32_t base = waveReserve(q.counters + RT_CNT_RAYS0 + level + 1, total);
-            uint32_t slot = base + maskRankBelow(mRefl) + maskRankBelow(mRefr);
+            uint32_t slot = offR + maskRankBelow(mRefl) + maskRankBelow(mRefr);
             if (emitRefl) {
                 if (slot < q.ray_cap) {
                     const V3 ro = P + RT_EPSILON * reflDir;  // main.cpp:155
@@ -496,7 +542,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, i
         culled += __shfl_down(culled, off);
         shaded += __shfl_down(shaded, off);
     }
-    if (laneId() == 0) {
+    if (lane == 0) {
         if (culled) atomicAdd(q.counters + RT_CNT_CULLED, culled);
         if (shaded) atomicAdd(q.counters + RT_CNT_SHADED, shaded);
     }
@@ -562,9 +608,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_assemble(int width, int height, in
 // ---------------------------------------------------------------------------------------------------------------
 // test hooks
 __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t root_ref, RtQueues q, uint32_t n,
-                                                     rt_hit *out_hits, uint8_t *out_shadow) {
-    extern __shared__ uint32_t s_stack[];
-    uint32_t *stack = s_stack + threadIdx.x;
+                                                     rt_hit *out_hits, uint8_t *out_shadow, int stack_entries) {
+    extern __shared__ uint32_t s_lds[];
+    uint32_t *stack = s_lds + threadIdx.x;
+    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
     RtTraversalStats st{0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 A = q.rayA[0][i], B = q.rayB[0][i];
@@ -603,7 +650,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t ro
                     bool s = true;
                     if (!(dot(normal, ld) < 0)) {
                         RtRay sr{h.P + RT_EPSILON * ld, ld};
-                        s = occluded<false>(sc, root_ref, sr, dl, stack, st);
+                        s = occluded<false>(sc, an, root_ref, sr, dl, stack, st);
                     }
                     sh[l] = s ? 1 : 0;
                 }
@@ -620,7 +667,7 @@ __global__ void k_rays_from_host(const float *rays, uint32_t n, RtQueues q) {
         q.rayA[0][i] = make_float4(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2], 1.0f);
         q.rayB[0][i] = make_float4(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5], __uint_as_float(i));
         q.rayR[0][i] = 1.0f;
-        if (i == 0) q.counters[RT_CNT_RAYS0] = n;
+        if (i == 0) q.counters[RT_CNT_RAYS(0)] = n;
     }
 }
 
@@ -650,14 +697,14 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
     hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles);
 }
 void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t);
-    if (stats) hipLaunchKernelGGL(k_closest<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
-    else hipLaunchKernelGGL(k_closest<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    if (stats) hipLaunchKernelGGL(k_closest<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
+    else hipLaunchKernelGGL(k_closest<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
 }
 void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t);
-    if (stats) hipLaunchKernelGGL(k_any<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
-    else hipLaunchKernelGGL(k_any<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level);
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    if (stats) hipLaunchKernelGGL(k_any<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
+    else hipLaunchKernelGGL(k_any<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
 }
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles) {
@@ -674,8 +721,8 @@ void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, 
 }
 void rtLaunchHitInfo(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, uint32_t n,
                      rt_hit *out_hits, uint8_t *out_shadow) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_hitinfo, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, n, out_hits, out_shadow);
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    hipLaunchKernelGGL(k_hitinfo, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, n, out_hits, out_shadow, cfg.stack_entries);
 }
 void rtLaunchRaysFromHost(const RtLaunchCfg &cfg, const float *d_rays, uint32_t n, const RtQueues &q) {
     hipLaunchKernelGGL(k_rays_from_host, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), 0, cfg.stream, d_rays, n, q);

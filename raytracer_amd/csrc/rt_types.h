@@ -41,11 +41,13 @@ struct RtTriShade {
     uint32_t _pad;
 };
 
-struct RtSphere {       // Objects.h:12-104
+struct RtSphere {       // Objects.h:12-104; 240 bytes
     float M[16], Minv[16], N[16];
     int32_t object;
     int32_t material;
-    int32_t _pad[2];
+    float box_mn[3], box_mx[3];  // padded world-space bounds of the transformed unit sphere (rt_commit): a ray that
+                                 // misses them cannot hit the sphere, so the exact test is skipped
+    int32_t _pad[4];
 };
 
 struct RtPlane {        // Objects.h:109-183
@@ -99,6 +101,7 @@ struct RtFrameDev {
 // ray flags packed above the sample index (28 bits of sample index)
 #define RT_SAMPLE_MASK 0x0FFFFFFFu
 #define RT_FLAG_HAS_REFR_SIBLING 0x10000000u  // reflection ray whose refraction sibling sits in the next slot
+#define RT_FLAG_INVALID 0x20000000u           // level-0 slot of a pixel outside the image: traced as a miss, never shaded
 
 // Wavefront queues of one chunk (device pointers).  Rays: A = (origin.xyz, weight), B = (direction.xyz, sample|flags),
 // R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (origin.xyz, light distance),
@@ -114,13 +117,16 @@ struct RtQueues {
     uint32_t ray_cap, shadow_cap;
 };
 
-enum RtCounter {
-    RT_CNT_RAYS0 = 0,          // rays in queue of level d at RT_CNT_RAYS0 + d (d = 0..15)
-    RT_CNT_SHADOW0 = 16,       // shadow rays of level d
-    RT_CNT_CULLED = 32,
-    RT_CNT_SHADED = 33,
-    RT_CNT_OVERFLOW = 34,
-    RT_CNT_NODES_LO = 36, RT_CNT_NODES_HI = 37, RT_CNT_TRIS_LO = 38, RT_CNT_TRIS_HI = 39,   // closest-hit rays
-    RT_CNT_ANY_NODES_LO = 40, RT_CNT_ANY_NODES_HI = 41, RT_CNT_ANY_TRIS_LO = 42, RT_CNT_ANY_TRIS_HI = 43,  // shadow rays
-    RT_CNT_WORDS = 64
-};
+// Device counters.  Every hot counter owns a 128-byte line: returning atomics on one line serialise at the memory
+// side (~10 ns each), so queue heads that are bumped from every CU must not share a line.
+#define RT_CNT_STRIDE 32
+#define RT_CNT_RAYS(d) ((d) * RT_CNT_STRIDE)                 // rays queued for level d (d = 0..15)
+#define RT_CNT_SHADOW(d) ((16 + (d)) * RT_CNT_STRIDE)        // shadow rays of level d
+#define RT_CNT_CULLED (32 * RT_CNT_STRIDE)
+#define RT_CNT_SHADED (33 * RT_CNT_STRIDE)
+#define RT_CNT_OVERFLOW (34 * RT_CNT_STRIDE)
+#define RT_CNT_INVALID (35 * RT_CNT_STRIDE)                  // level-0 slots outside the image (ragged edge tiles)
+#define RT_CNT_NODES (36 * RT_CNT_STRIDE)                    // u64 nodes at +0, u64 triangle tests at +2 (closest rays)
+#define RT_CNT_ANY_NODES (37 * RT_CNT_STRIDE)                // same for shadow rays
+#define RT_CNT_WORDS (40 * RT_CNT_STRIDE)
+
