@@ -108,6 +108,7 @@ typedef struct rt_stats {
     uint64_t bvh_nodes, bvh_depth, n_triangles;
     uint64_t nodes_visited_any; /* BVH nodes fetched by shadow rays (collect_stats & 1 only) */
     uint64_t tris_tested_any;   /* triangle tests of shadow rays    (collect_stats & 1 only) */
+    uint64_t bvh_max_stack;     /* traversal stack entries a ray can need in this BVH */
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */
@@ -168,7 +169,7 @@ int rt_set_lights(rt_context *ctx, int32_t n, const float *position, const float
 int rt_set_bmp(rt_context *ctx, int32_t slot, int32_t width, int32_t height, int32_t channels,
                const uint8_t *bytes);
 
-/* Flatten check, BVH build (linear 32-byte nodes), upload.  Must precede rendering; may be repeated. */
+/* Flatten check, BVH build (linear array of 64-byte 4-wide nodes), upload.  Must precede rendering; may be repeated. */
 int rt_commit(rt_context *ctx);
 
 /* -- the render loop: stands in for main.cpp:607-650 (+ toneMapping :240, Image::setPixel Image.h:91-95) -- */
@@ -209,8 +210,9 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
 int rt_eval_texture(rt_context *ctx, int32_t texture_id, int64_t n, const float *uv, float *out);
 int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out);
 
-/* Read back the committed BVH (for the oracle-side counter checks): nodes[n_nodes*8] floats as stored,
- * tri_order[n_triangles] = global triangle index held by BVH slot i.  Pass NULL to query sizes only. */
+/* Read back the committed BVH (for the oracle-side counter checks): nodes[n_nodes*16] 32-bit words as stored
+ * (64-byte 4-wide quantised nodes, layout in DESIGN.md), tri_order[n_triangles] = global triangle index held by
+ * BVH slot i.  Pass NULL to query sizes only. */
 int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order);
 
 #ifdef __cplusplus

@@ -77,8 +77,8 @@ struct rt_context {
     bool committed = false;
     RtBvh bvh;
     std::vector<int64_t> mesh_first;  // per object: first global triangle index (or -1)
-    DevBuf<RtNode> d_nodes;
-    DevBuf<RtTriGeom> d_geom;
+    DevBuf<RtNode4> d_records;  // BVH nodes, then the triangle records (rt_types.h)
+    DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part
     DevBuf<RtTriShade> d_shade;
     DevBuf<RtSphere> d_spheres;
     DevBuf<RtPlane> d_planes;
@@ -139,6 +139,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     q.shC = ctx->d_shC.p;
     q.accum = ctx->d_accum.p;
     q.counters = ctx->d_counters.p;
+    q.spill = ctx->d_spill.p;
     q.ray_cap = (uint32_t)ray_cap;
     q.shadow_cap = (uint32_t)sh_cap;
     return 0;
@@ -192,11 +193,13 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
 void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
-               bool stats, KernelTimer &kt, rt_stats *st) {
+               bool stats, KernelTimer &kt, rt_stats *st, bool level0_traced = false) {
     for (int level = 0; level <= max_depth; level++) {
-        kt.begin(1);
-        rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
-        kt.end();
+        if (!(level == 0 && level0_traced)) {  // each level's queue is claimed once (dynamic fetch counters)
+            kt.begin(1);
+            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
+            kt.end();
+        }
         kt.begin(2);
         rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles);
         kt.end();
@@ -243,7 +246,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     int64_t n_local = 0, n_total = 0;
     rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, &n_total);
     const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
-    size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 21;
+    size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 24;
     chunk_samples = std::min<size_t>(chunk_samples, RT_SAMPLE_MASK);
     size_t chunk_tiles = std::max<size_t>(1, chunk_samples / per_tile);
     chunk_tiles = std::min<size_t>(chunk_tiles, std::max<int64_t>(n_local, 1));
@@ -308,6 +311,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     }
     st->bvh_nodes = ctx->bvh.nodes.size();
     st->bvh_depth = ctx->bvh.depth;
+    st->bvh_max_stack = ctx->bvh.max_stack;
     st->n_triangles = ctx->tri_flags.size();
     if (st->queue_overflow) return fail("wavefront queue overflow (" + std::to_string(st->queue_overflow) + " rays dropped)");
     return 0;
@@ -343,7 +347,7 @@ int rt_destroy(rt_context *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->d_nodes.release(); ctx->d_geom.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
+    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
@@ -381,7 +385,7 @@ int rt_set_triangles(rt_context *ctx, int64_t n, const float *v0, const float *v
                      const float *nB, const float *nC, const float *tA, const float *tB, const float *tC,
                      const uint32_t *flags, const int32_t *object_id) {
     if (!ctx || n < 0) return fail("rt_set_triangles: bad arguments");
-    if (n >= (1ll << 28)) return fail("rt_set_triangles: at most 2^28-1 triangles");
+    if (n >= (1ll << 27)) return fail("rt_set_triangles: at most 2^27-1 triangles (28-bit record index: nodes + triangles)");
     if (n && (!v0 || !v1 || !v2 || !flags || !object_id)) return fail("rt_set_triangles: NULL vertex/flags/object arrays");
     auto put = [&](std::vector<float> &dst, const float *src, int w) {
         dst.assign((size_t)n * w, 0.0f);
@@ -490,7 +494,13 @@ int rt_commit(rt_context *ctx) {
     rtReferenceOrder(nt, ctx->v0.data(), ctx->v1.data(), ctx->v2.data(), ctx->tri_object.data(), rank.data());
     ctx->mesh_first.assign(n_obj, -1);
     for (int64_t k = nt - 1; k >= 0; k--) ctx->mesh_first[ctx->tri_object[k]] = k;
-    std::vector<RtTriGeom> geom((size_t)nt);
+    // record array: nodes first, then one 64-byte record per triangle in leaf (slot) order
+    const size_t nn = ctx->bvh.nodes.size();
+    static_assert(sizeof(RtNode4) == 64 && sizeof(RtTriGeom) == 64, "records are 64 bytes");
+    if (nn + (size_t)nt >= (1ull << 28)) return fail("rt_commit: more than 2^28 BVH records");
+    std::vector<RtNode4> records(nn + (size_t)nt);
+    if (nn) std::memcpy(records.data(), ctx->bvh.nodes.data(), nn * sizeof(RtNode4));
+    RtTriGeom *geom = reinterpret_cast<RtTriGeom *>(records.data() + nn);
     std::vector<RtTriShade> shade((size_t)nt);
     for (int64_t slot = 0; slot < nt; slot++) {
         const size_t t = ctx->bvh.order[slot];
@@ -504,6 +514,10 @@ int rt_commit(rt_context *ctx) {
         g.q0[0] = A[0]; g.q0[1] = A[1]; g.q0[2] = A[2]; g.q0[3] = cx * inv;
         g.q1[0] = B[0]; g.q1[1] = B[1]; g.q1[2] = B[2]; g.q1[3] = cy * inv;
         g.q2[0] = C[0]; g.q2[1] = C[1]; g.q2[2] = C[2]; g.q2[3] = cz * inv;
+        g.object = (uint32_t)ctx->tri_object[t];
+        g.rank = rank[t];
+        g.prim = (uint32_t)t;
+        g._pad = 0;
         RtTriShade &s = shade[slot];
         std::memcpy(s.nA, &ctx->nA[3 * t], 12); std::memcpy(s.nB, &ctx->nB[3 * t], 12); std::memcpy(s.nC, &ctx->nC[3 * t], 12);
         std::memcpy(s.tA, &ctx->tA[2 * t], 8); std::memcpy(s.tB, &ctx->tB[2 * t], 8); std::memcpy(s.tC, &ctx->tC[2 * t], 8);
@@ -513,7 +527,7 @@ int rt_commit(rt_context *ctx) {
         s.rank = rank[t];
         s._pad = 0;
     }
-    if (ctx->d_nodes.upload(ctx->bvh.nodes) || ctx->d_geom.upload(geom) || ctx->d_shade.upload(shade)) return 1;
+    if (ctx->d_records.upload(records) || ctx->d_shade.upload(shade)) return 1;
     if (ctx->d_spheres.upload(ctx->spheres) || ctx->d_planes.upload(ctx->planes)) return 1;
     if (ctx->d_materials.upload(ctx->materials) || ctx->d_objmat.upload(ctx->object_material) || ctx->d_lights.upload(ctx->lights)) return 1;
     RtSceneDev &d = ctx->dev;
@@ -525,8 +539,9 @@ int rt_commit(rt_context *ctx) {
         }
         d.bmp_w[k] = ctx->bmp_w[k]; d.bmp_h[k] = ctx->bmp_h[k]; d.bmp_c[k] = ctx->bmp_c[k];
     }
-    d.nodes = ctx->d_nodes.p;
-    d.tri_geom = ctx->d_geom.p;
+    d.nodes = ctx->d_records.p;
+    d.tri_geom = reinterpret_cast<const RtTriGeom *>(ctx->d_records.p + nn);
+    d.bound = ctx->bvh.bound;
     d.tri_shade = ctx->d_shade.p;
     d.spheres = ctx->d_spheres.p;
     d.planes = ctx->d_planes.p;
@@ -541,14 +556,19 @@ int rt_commit(rt_context *ctx) {
     d.n_lights = (int)ctx->lights.size();
     d.n_objects = n_obj;
     d.n_materials = n_mat;
-    // LDS traversal stack: entries >= tree depth; 256 B per entry per wave, 160 KB per CU
-    int entries = 8;
-    while (entries < ctx->bvh.depth + 1) entries += 8;
-    if (entries > 160) return fail("rt_commit: BVH deeper than the LDS stack budget");
+    // traversal stack: the worst case (sum of children - 1 along the deepest path) lives in LDS when it fits
+    // RT_LDS_STACK_MAX rows (branch-free kernels); deeper scenes keep RT_LDS_STACK rows in LDS and spill the rest to a
+    // global area per grid thread
+    const bool spills = ctx->bvh.max_stack > RT_LDS_STACK_MAX;
+    const int entries = spills ? RT_LDS_STACK : std::max(1, ctx->bvh.max_stack);
     ctx->cfg.stack_entries = entries;
+    ctx->cfg.stack_spills = spills;
     ctx->cfg.analytic_bytes = (int)(ctx->spheres.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
-    const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
+    const int lds_per_block = (entries + 1) * 256 * 4 + ctx->cfg.analytic_bytes;
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
+    const size_t spill_entries = (size_t)std::max(0, ctx->bvh.max_stack - entries);
+    if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;
+    ctx->q.spill = ctx->d_spill.p;
     ctx->committed = true;
     return 0;
 }
@@ -635,7 +655,7 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
         // level 0 closest hit first: the hit records of the batch are reported from it
         rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, false);
         if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
-        runLevels(ctx, cfg, depth, 1, 0, nullptr, false, kt, st);
+        runLevels(ctx, cfg, depth, 1, 0, nullptr, false, kt, st, true);
         rtLaunchBatchColors(cfg, ctx->q, m, d_col.p);
         std::vector<uint32_t> hc(RT_CNT_WORDS);
         e = hipStreamSynchronize(cfg.stream);
@@ -655,7 +675,6 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
     }
     d_rays.release(); d_col.release(); d_hits.release(); d_sh.release();
     st->primary_samples = (uint64_t)n;
-    // the extra level-0 launch above is not double counted: runLevels re-traces level 0 into the same records
     if (!rc && st->queue_overflow) rc = fail("wavefront queue overflow");
     return rc;
 }
@@ -709,7 +728,7 @@ int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_trian
     if (!ctx || !ctx->committed) return fail("rt_get_bvh: no committed scene");
     if (n_nodes) *n_nodes = (int64_t)ctx->bvh.nodes.size();
     if (n_triangles) *n_triangles = (int64_t)ctx->bvh.order.size();
-    if (nodes && !ctx->bvh.nodes.empty()) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(RtNode));
+    if (nodes && !ctx->bvh.nodes.empty()) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(RtNode4));
     if (tri_order && !ctx->bvh.order.empty()) std::memcpy(tri_order, ctx->bvh.order.data(), ctx->bvh.order.size() * sizeof(uint32_t));
     return 0;
 }

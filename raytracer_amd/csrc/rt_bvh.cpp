@@ -2,9 +2,10 @@
 //
 // Replaces the reference's per-mesh pointer tree (bvh_node, MeshLoader.h:211-285: split at the mean vertex
 // coordinate, axis cycling with depth, leaves of <= 100 triangles that are copied by value per visit) with ONE
-// binned-SAH tree over every triangle of the scene, stored as 32-byte nodes in a flat array:
-//   * node 0 is padding, the root is node 1, and the two children of an inner node are adjacent at an even index,
-//     so a sibling pair is exactly one 64-byte line and one fetch per traversal step;
+// binned-SAH binary tree over every triangle of the scene, collapsed into a 4-wide tree of 64-byte nodes whose
+// child boxes are quantised to 8 bits per plane (rt_types.h: RtNode4):
+//   * one node = one cache line = one fetch per traversal step, and about half the steps of the binary tree;
+//   * quantisation rounds outwards in exact arithmetic (scale is a power of two), so boxes stay conservative;
 //   * leaves hold <= RT_LEAF_MAX triangles that are contiguous in the reordered triangle array.
 // The reference's tree is not reproduced -- only its observable result is (closest / any hit), plus the ORDER in
 // which it hands out candidates, because that order decides exact distance ties (MeshLoader.h:399-404):
@@ -177,12 +178,95 @@ void refOrder(const float *v0, const float *v1, const float *v2, std::vector<uin
     refOrder(v0, v1, v2, right, (a + 1) % 3, depth + 1, next, rank);
 }
 
+
+// ---- collapse to 4 children per node + quantisation -------------------------------------------------------------
+struct Collapser {
+    const std::vector<RtNode> &bn;
+    std::vector<RtNode4> out;
+    int maxDepth = 0, maxStack = 0;
+    float bound = 0.0f;
+
+    static float halfArea(const RtNode &n) {
+        const float dx = n.mx[0] - n.mn[0], dy = n.mx[1] - n.mn[1], dz = n.mx[2] - n.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static uint32_t leafRef(const RtNode &n) { return 0x80000000u | ((n.b - 1u) << 28) | n.a; }  // slot; rebased later
+
+    // emits the 4-wide node of binary inner node `b`; `pending` = stack entries that can be live above it
+    uint32_t emit(uint32_t b, int depth, int pending) {
+        const uint32_t self = (uint32_t)out.size();
+        out.emplace_back();
+        uint32_t kids[4] = {bn[b].a, bn[b].a + 1, 0, 0};
+        int nk = 2;
+        while (nk < 4) {  // open the inner child with the largest surface
+            int pick = -1;
+            float best = -1.0f;
+            for (int k = 0; k < nk; k++)
+                if (bn[kids[k]].b == 0 && halfArea(bn[kids[k]]) > best) {
+                    best = halfArea(bn[kids[k]]);
+                    pick = k;
+                }
+            if (pick < 0) break;
+            const uint32_t open = kids[pick];
+            for (int k = nk; k > pick + 1; k--) kids[k] = kids[k - 1];
+            kids[pick] = bn[open].a;
+            kids[pick + 1] = bn[open].a + 1;
+            nk++;
+        }
+        maxDepth = std::max(maxDepth, depth);
+        maxStack = std::max(maxStack, pending + nk - 1);
+        // frame = union of the children's (padded) boxes
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < nk; k++)
+            for (int a = 0; a < 3; a++) {
+                lo[a] = std::fmin(lo[a], bn[kids[k]].mn[a]);
+                hi[a] = std::fmax(hi[a], bn[kids[k]].mx[a]);
+            }
+        double scale[3];
+        for (int a = 0; a < 3; a++) {
+            bound = std::fmax(bound, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+            const double ext = (double)hi[a] - (double)lo[a];
+            int e = -100;
+            if (ext > 0) e = std::max(-100, (int)std::ceil(std::log2(ext / 255.0)));
+            while (ext / std::ldexp(1.0, e) > 255.0) e++;
+            scale[a] = std::ldexp(1.0, e);
+        }
+        uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+        uint32_t child[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (int k = 0; k < nk; k++) {
+            const RtNode &c = bn[kids[k]];
+            for (int a = 0; a < 3; a++) {
+                double l = std::floor(((double)c.mn[a] - (double)lo[a]) / scale[a]);
+                double h = std::ceil(((double)c.mx[a] - (double)lo[a]) / scale[a]);
+                l = std::fmin(std::fmax(l, 0.0), 255.0);
+                h = std::fmin(std::fmax(h, 0.0), 255.0);
+                qlo[a] |= (uint32_t)l << (8 * k);
+                qhi[a] |= (uint32_t)h << (8 * k);
+            }
+        }
+        for (int k = 0; k < nk; k++) {
+            const RtNode &c = bn[kids[k]];
+            child[k] = c.b ? leafRef(c) : emit(kids[k], depth + 1, pending + nk - 1);
+        }
+        RtNode4 &n = out[self];
+        n.origin[0] = lo[0]; n.origin[1] = lo[1]; n.origin[2] = lo[2];
+        n.scale_x = (float)scale[0]; n.scale_y = (float)scale[1]; n.scale_z = (float)scale[2];
+        for (int k = 0; k < 4; k++) n.child[k] = child[k];
+        n.qlo[0] = qlo[0]; n.qlo[1] = qlo[1]; n.qlo[2] = qlo[2];
+        n.qhi_x = qhi[0]; n.qhi_y = qhi[1]; n.qhi_z = qhi[2];
+        return self;
+    }
+};
+
 }  // namespace
 
 void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, RtBvh &out) {
     out.nodes.clear();
     out.order.clear();
     out.depth = 0;
+    out.max_stack = 0;
+    out.bound = 0.0f;
+    out.binary_nodes = 0;
     out.root_ref = 0xFFFFFFFFu;
     if (n <= 0) return;
     Builder b;
@@ -202,11 +286,30 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     b.nodes.resize(2);  // [0] padding so that sibling pairs start at even indices, [1] root
     std::memset(b.nodes.data(), 0, 2 * sizeof(RtNode));
     b.build(1, 0, (uint32_t)n, 0);
-    out.nodes = std::move(b.nodes);
     out.order = std::move(b.index);
-    out.depth = b.maxDepth;
-    const RtNode &root = out.nodes[1];
-    out.root_ref = root.b == 0 ? root.a : (0x80000000u | ((root.b - 1u) << 28) | root.a);
+    out.binary_nodes = (int64_t)b.nodes.size();
+    const RtNode &root = b.nodes[1];
+    if (root.b) {  // the whole scene is one leaf
+        out.root_ref = Collapser::leafRef(root);
+        out.depth = 0;
+        out.max_stack = 0;
+        for (int a = 0; a < 3; a++) out.bound = std::fmax(out.bound, std::fmax(std::fabs(root.mn[a]), std::fabs(root.mx[a])));
+    } else {
+        Collapser c{b.nodes};
+        c.out.reserve(b.nodes.size() / 2 + 1);
+        c.emit(1, 1, 0);
+        out.nodes = std::move(c.out);
+        out.root_ref = 0;
+        out.depth = c.maxDepth;
+        out.max_stack = c.maxStack;
+        out.bound = c.bound;
+    }
+    // triangle records follow the nodes in the record array: rebase the leaf references
+    const uint32_t base = (uint32_t)out.nodes.size();
+    for (RtNode4 &nd : out.nodes)
+        for (int k = 0; k < 4; k++)
+            if (nd.child[k] != 0xFFFFFFFFu && (nd.child[k] & 0x80000000u)) nd.child[k] += base;
+    if (out.root_ref & 0x80000000u) out.root_ref += base;
 }
 
 void rtReferenceOrder(int64_t n, const float *v0, const float *v1, const float *v2, const int32_t *object_id,

@@ -5,10 +5,13 @@
 #include "rt_types.h"
 
 struct RtBvh {
-    std::vector<RtNode> nodes;    // [0] padding, [1] root, sibling pairs adjacent at even indices
+    std::vector<RtNode4> nodes;   // 4-wide quantised nodes, root = node 0 (rt_types.h: RtNode4)
     std::vector<uint32_t> order;  // slot -> input triangle index (triangles are re-ordered into leaf order)
-    uint32_t root_ref = 0xFFFFFFFFu;  // traversal reference word of the root (rt_kernels.hip: nodeRef)
-    int depth = 0;                // maximum leaf depth = LDS stack entries a traversal can need
+    uint32_t root_ref = 0xFFFFFFFFu;  // reference word of the root: node 0, or a leaf when the scene has <= 4 triangles
+    int depth = 0;                // maximum depth of the 4-wide tree
+    int max_stack = 0;            // stack entries a near-first walk can need: max over paths of sum(children - 1)
+    float bound = 0.0f;           // max |coordinate| of any node box
+    int64_t binary_nodes = 0;     // size of the binary SAH tree the 4-wide tree was collapsed from
 };
 
 void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, RtBvh &out);

@@ -17,8 +17,6 @@
 #include "rt_kernels.h"
 
 #define RT_BLOCK 256
-#define RT_NODE_LEAF 0x80000000u
-#define RT_NODE_DONE 0xFFFFFFFFu
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -34,23 +32,34 @@ RT_DEV uint32_t waveReserve(uint32_t *counter, uint32_t total) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// BVH traversal
+// BVH traversal: 4-wide quantised nodes and triangle records in ONE array of 64-byte records (rt_types.h).  A step
+// fetches the record the lane's `cur` refers to -- four 16-byte loads issued by every lane of the wave together,
+// whether the lane is at a node or at a triangle -- and then either tests the four child boxes (near-first
+// descent, the other hit children pushed far-first) or runs the reference's exact triangle test.
 struct RtTraversalStats { uint32_t nodes, tris; };
 
-RT_DEV uint32_t nodeRef(float4 lo, float4 hi) {  // reference word of a node: inner -> child pair index, leaf -> packed range
-    const uint32_t a = __float_as_uint(lo.w), b = __float_as_uint(hi.w);
-    return b == 0 ? a : (RT_NODE_LEAF | ((b - 1u) << 28) | a);
+struct RtStack {          // per-lane stack: the first `lds_entries` live in LDS ([entry][lane], conflict free),
+    uint32_t *lds;        // deeper ones in a global spill area ([entry][grid thread], coalesced)
+    uint32_t *spill;
+    uint32_t spill_stride;
+    int lds_entries;
+};
+RT_DEV void rtPush(const RtStack &s, int &sp, uint32_t v) {
+    if (sp < s.lds_entries) s.lds[sp * RT_BLOCK] = v;
+    else s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride] = v;
+    sp++;
 }
-
-// slab test against [tlo, thi]; entry distance in tnear.  Precomputed inv = 1/d and oi = o*inv (one fma per plane).
-RT_DEV bool slabHit(float4 lo, float4 hi, V3 inv, V3 oi, float thi, float &tnear) {
-    float ax = __builtin_fmaf(lo.x, inv.x, -oi.x), bx = __builtin_fmaf(hi.x, inv.x, -oi.x);
-    float ay = __builtin_fmaf(lo.y, inv.y, -oi.y), by = __builtin_fmaf(hi.y, inv.y, -oi.y);
-    float az = __builtin_fmaf(lo.z, inv.z, -oi.z), bz = __builtin_fmaf(hi.z, inv.z, -oi.z);
-    float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), thi));
-    tnear = tmin;
-    return tmin <= tmax * 1.0000005f;  // node boxes are also padded at build time (rt_bvh.cpp)
+RT_DEV uint32_t rtPop(const RtStack &s, int &sp) {  // requires sp > 0
+    --sp;
+    return sp < s.lds_entries ? s.lds[sp * RT_BLOCK] : s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride];
+}
+RT_DEV RtStack rtMakeStack(uint32_t *lds_base, uint32_t *spill, int lds_entries) {
+    RtStack s;
+    s.lds = lds_base + threadIdx.x;
+    s.spill = spill + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    s.spill_stride = gridDim.x * RT_BLOCK;
+    s.lds_entries = lds_entries;
+    return s;
 }
 
 RT_DEV float safeInv(float d) {
@@ -61,73 +70,137 @@ RT_DEV float safeInv(float d) {
     return inv;
 }
 
-// ANY = false: closest hit with the reference's tie rule; ANY = true: first hit with t <= tmax ends the walk.
-// `stack` points at this lane's column of the block's LDS stack (stride RT_BLOCK words).
-template <bool ANY, bool STATS>
-RT_DEV bool traverseBvh(const RtSceneDev &sc, uint32_t root_ref, const RtRay &r, V3 inv, V3 oi, float &best_t,
-                        uint32_t &best_id, uint32_t *stack, RtTraversalStats &st) {
-    if (sc.n_tris == 0) return false;
-    const float4 *nodes = reinterpret_cast<const float4 *>(sc.nodes);
-    uint32_t cur = root_ref;
-    int sp = 0;
-    bool found = false;
-    while (cur != RT_NODE_DONE) {
-        while (!(cur & RT_NODE_LEAF)) {  // inner node: cur = index of its left child; the sibling pair is one 64-B line
-            const float4 l0 = nodes[2 * cur], l1 = nodes[2 * cur + 1], r0 = nodes[2 * cur + 2], r1 = nodes[2 * cur + 3];
-            if (STATS) st.nodes += 2;
-            float tl, tr;
-            const bool hl = slabHit(l0, l1, inv, oi, best_t, tl);
-            const bool hr = slabHit(r0, r1, inv, oi, best_t, tr);
-            const uint32_t rl = nodeRef(l0, l1), rr = nodeRef(r0, r1);
-            if (hl && hr) {
-                const bool leftFirst = tl <= tr;
-                stack[sp * RT_BLOCK] = leftFirst ? rr : rl;
-                sp++;
-                cur = leftFirst ? rl : rr;
-            } else if (hl) {
-                cur = rl;
-            } else if (hr) {
-                cur = rr;
-            } else {
-                cur = sp ? stack[(--sp) * RT_BLOCK] : RT_NODE_DONE;
-            }
-        }
-        if (cur != RT_NODE_DONE) {  // leaf
-            const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
-            for (uint32_t k = 0; k < cnt; k++) {
-                const uint32_t slot = first + k;
-                const RtTri T = rtLoadTri(sc.tri_geom, slot);
-                if (STATS) st.tris++;
-                float t;
-                if (!rtTriHit(T, r, best_t, t)) continue;
-                if (ANY) {
-                    found = true;
-                    break;
-                }
-                bool take = t < best_t;
-                if (!take && t == best_t) {
-                    // exact tie: the earlier object wins (main.cpp:67), inside a mesh the earlier candidate in the
-                    // reference's order wins (MeshLoader.h:399-404)
-                    const RtTriShade &s = sc.tri_shade[slot];
-                    unsigned long long mine = ((unsigned long long)(uint32_t)s.object << 32) | s.rank, theirs;
-                    const uint32_t kind = best_id & RT_ID_KIND_MASK;
-                    if (best_id == RT_ID_MISS) theirs = ~0ull;
-                    else if (kind == RT_ID_SPHERE) theirs = (unsigned long long)(uint32_t)sc.spheres[best_id & 0xFFFF].object << 32;
-                    else if (kind == RT_ID_PLANE) theirs = (unsigned long long)(uint32_t)sc.planes[best_id & 0xFFFF].object << 32;
-                    else theirs = ((unsigned long long)(uint32_t)sc.tri_shade[best_id].object << 32) | sc.tri_shade[best_id].rank;
-                    take = mine < theirs;
-                }
-                if (take) {
-                    best_t = t;
-                    best_id = slot;
-                    found = true;
-                }
-            }
-            if (ANY && found) break;
-            cur = sp ? stack[(--sp) * RT_BLOCK] : RT_NODE_DONE;
-        }
+struct RtWalk {  // per-lane traversal state
+    RtRay r;
+    V3 inv, oi, err;   // 1/d, o/d and the per-axis error bound of a plane distance
+    float best_t;      // closest hit so far (closest) or the light distance (any-hit)
+    uint32_t best_id;
+    int best_obj;      // object and reference candidate rank of the best hit: the exact-tie rule needs them
+    uint32_t best_rank;
+    uint32_t cur;      // record reference: node index, RT_NODE_LEAF | (triangles left - 1) << 28 | record index, or DONE
+    int sp;
+};
+
+// Plane distances are t = fma(q, scale/d, fma(origin, 1/d, -o/d)): the product q*scale is exact, so the absolute
+// error is at most 2^-24 (2|o/d| + |origin/d| + 2|t|).  err covers the first two terms with margin (applied per axis:
+// near planes move towards the origin, far planes away), the factor on tfar covers the relative one.
+RT_DEV void rtInitWalk(const RtSceneDev &sc, RtWalk &w, uint32_t root_ref) {
+    w.inv = v3(safeInv(w.r.d.x), safeInv(w.r.d.y), safeInv(w.r.d.z));
+    w.oi = v3(w.r.o.x * w.inv.x, w.r.o.y * w.inv.y, w.r.o.z * w.inv.z);
+    const float u = 4.76837158e-07f;  // 2^-21
+    w.err = v3((fabsf(w.oi.x) + sc.bound * fabsf(w.inv.x)) * u, (fabsf(w.oi.y) + sc.bound * fabsf(w.inv.y)) * u,
+               (fabsf(w.oi.z) + sc.bound * fabsf(w.inv.z)) * u);
+    w.sp = 0;
+    w.cur = sc.n_tris ? root_ref : RT_NODE_DONE;
+}
+
+RT_DEV float ubyteF(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xFFu); }  // v_cvt_f32_ubyte{c}
+
+// One traversal step.  Returns true when an any-hit ray is occluded; otherwise w.cur is the next record or DONE.
+// SPILL = false (the scene's worst-case stack fits the LDS rows): the step is branch-free apart from the node /
+// triangle split -- the stack top is read speculatively together with the record, pushes are three unconditional
+// LDS stores (entries that do not exist go to a dummy row).  SPILL = true keeps conditional pushes / pops that fall
+// through to the global spill area.
+template <bool ANY, bool STATS, bool SPILL>
+RT_DEV bool rtStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTraversalStats &st) {
+    // exactly four 16-byte loads per lane, issued before the node / triangle split; the empty asm pins them as whole
+    // registers (left alone, the compiler re-slices the record into six narrower loads: 50 % more L1 accesses)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *rec = reinterpret_cast<const v4f *>(sc.nodes) + 4 * (size_t)(w.cur & RT_NODE_INDEX_MASK);
+    v4f q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    uint32_t popped = RT_NODE_DONE;
+    if (!SPILL) {
+        const uint32_t top = stk.lds[(max(w.sp, 1) - 1) * RT_BLOCK];
+        popped = w.sp ? top : RT_NODE_DONE;
     }
-    return found;
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+    if (w.cur & RT_NODE_LEAF) {  // triangle record
+        if (STATS) st.tris++;
+        RtTri T;
+        T.A = v3(q0.x, q0.y, q0.z);
+        T.B = v3(q1.x, q1.y, q1.z);
+        T.C = v3(q2.x, q2.y, q2.z);
+        T.n = v3(q0.w, q1.w, q2.w);
+        float t;
+        if (rtTriHit(T, w.r, w.best_t, t)) {
+            if (ANY) return true;
+            const int obj = (int)__float_as_uint(q3.x);
+            const uint32_t rank = __float_as_uint(q3.y);
+            // strict minimum; on an exact tie the earlier object wins (main.cpp:67) and inside a mesh the earlier
+            // candidate of the reference's order (MeshLoader.h:399-404).  A miss (distance INFINITY) never loses to inf.
+            const bool take = t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
+                                               (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
+            if (take) {
+                w.best_t = t;
+                w.best_id = (w.cur & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes;
+                w.best_obj = obj;
+                w.best_rank = rank;
+            }
+        }
+        if ((w.cur >> 28) & 7u) {  // next triangle of the leaf
+            w.cur += 1u - 0x10000000u;
+        } else if (SPILL) {
+            w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
+        } else {
+            w.cur = popped;
+            w.sp = max(w.sp - 1, 0);
+        }
+        return false;
+    }
+    if (STATS) st.nodes++;
+    const V3 m = v3(q0.w * w.inv.x, q3.z * w.inv.y, q3.w * w.inv.z);  // scale / d (scale is a power of two: exact)
+    const float ax = __builtin_fmaf(q0.x, w.inv.x, -w.oi.x), ay = __builtin_fmaf(q0.y, w.inv.y, -w.oi.y),
+                az = __builtin_fmaf(q0.z, w.inv.z, -w.oi.z);
+    const bool negx = w.inv.x < 0.0f, negy = w.inv.y < 0.0f, negz = w.inv.z < 0.0f;
+    const uint32_t lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
+    const uint32_t hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
+    const uint32_t nrx = negx ? hix : lox, frx = negx ? lox : hix;
+    const uint32_t nry = negy ? hiy : loy, fry = negy ? loy : hiy;
+    const uint32_t nrz = negz ? hiz : loz, frz = negz ? loz : hiz;
+    const float anx = ax - w.err.x, afx = ax + w.err.x, any_ = ay - w.err.y, afy = ay + w.err.y, anz = az - w.err.z,
+                afz = az + w.err.z;
+    uint32_t ref[4] = {__float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z), __float_as_uint(q1.w)};
+    uint32_t key[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float tnx = __builtin_fmaf(ubyteF(nrx, c), m.x, anx), tfx = __builtin_fmaf(ubyteF(frx, c), m.x, afx);
+        const float tny = __builtin_fmaf(ubyteF(nry, c), m.y, any_), tfy = __builtin_fmaf(ubyteF(fry, c), m.y, afy);
+        const float tnz = __builtin_fmaf(ubyteF(nrz, c), m.z, anz), tfz = __builtin_fmaf(ubyteF(frz, c), m.z, afz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, w.best_t)) * 1.000001f;
+        const bool hit = tn <= tf && ref[c] != 0xFFFFFFFFu;
+        key[c] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;  // tn >= 0: bit order == value order
+    }
+    // sort (entry distance, reference) pairs: 5 comparators
+#define RT_CSWAP(i, j)                                                            \
+    {                                                                             \
+        const bool sw = key[j] < key[i];                                          \
+        const uint32_t ki = sw ? key[j] : key[i], kj = sw ? key[i] : key[j];      \
+        const uint32_t ri = sw ? ref[j] : ref[i], rj = sw ? ref[i] : ref[j];      \
+        key[i] = ki; key[j] = kj; ref[i] = ri; ref[j] = rj;                       \
+    }
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+    if (SPILL) {
+        if (key[0] == 0xFFFFFFFFu) {
+            w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
+        } else {
+            if (key[3] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[3]);
+            if (key[2] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[2]);
+            if (key[1] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[1]);
+            w.cur = ref[0];
+        }
+    } else {
+        // far-first pushes of the hit children 1..n-1: child k goes to entry sp + n-1-k; the rest to the dummy row
+        const int n = (key[0] != 0xFFFFFFFFu) + (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
+        const int top = w.sp + n - 1, dummy = stk.lds_entries;
+        stk.lds[(n > 1 ? top - 1 : dummy) * RT_BLOCK] = ref[1];
+        stk.lds[(n > 2 ? top - 2 : dummy) * RT_BLOCK] = ref[2];
+        stk.lds[(n > 3 ? top - 3 : dummy) * RT_BLOCK] = ref[3];
+        w.cur = n ? ref[0] : popped;
+        w.sp = n ? top : max(w.sp - 1, 0);
+    }
+    return false;
 }
 
 // Analytic primitives are staged once per block into LDS (a few hundred bytes; every lane of every ray reads all of
@@ -145,64 +218,74 @@ RT_DEV RtAnalytic stageAnalytic(const RtSceneDev &sc, uint32_t *lds_after_stack)
     __syncthreads();
     return RtAnalytic{reinterpret_cast<const RtSphere *>(dst), reinterpret_cast<const RtPlane *>(dst + nsw)};
 }
+// padded world box of a sphere: a ray that misses it cannot hit the sphere (plain slab test, no quantisation)
 RT_DEV bool sphereBoxHit(const RtSphere &sp, V3 inv, V3 oi) {
-    float tn;
-    return slabHit(make_float4(sp.box_mn[0], sp.box_mn[1], sp.box_mn[2], 0.0f), make_float4(sp.box_mx[0], sp.box_mx[1], sp.box_mx[2], 0.0f),
-                   inv, oi, INFINITY, tn);
+    const float ax = __builtin_fmaf(sp.box_mn[0], inv.x, -oi.x), bx = __builtin_fmaf(sp.box_mx[0], inv.x, -oi.x);
+    const float ay = __builtin_fmaf(sp.box_mn[1], inv.y, -oi.y), by = __builtin_fmaf(sp.box_mx[1], inv.y, -oi.y);
+    const float az = __builtin_fmaf(sp.box_mn[2], inv.z, -oi.z), bz = __builtin_fmaf(sp.box_mx[2], inv.z, -oi.z);
+    const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tmin <= tmax * 1.0000005f;
 }
 
-// closest(): analytic primitives in scene order, then the triangle BVH (ties resolved by object order above)
-template <bool STATS>
-RT_DEV void closestHit(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtRay &r, float &best_t,
-                       uint32_t &best_id, uint32_t *stack, RtTraversalStats &st) {
-    best_t = INFINITY;
-    best_id = RT_ID_MISS;
-    int best_obj = 0x7FFFFFFF;
-    const V3 inv = v3(safeInv(r.d.x), safeInv(r.d.y), safeInv(r.d.z));
-    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+// closest() over the analytic primitives, in scene order (ties resolved by object order, main.cpp:67)
+RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &w) {
+    w.best_t = INFINITY;
+    w.best_id = RT_ID_MISS;
+    w.best_obj = 0x7FFFFFFF;
+    w.best_rank = 0;
     for (int k = 0; k < sc.n_spheres; k++) {
         const RtSphere &sp = an.spheres[k];
-        if (!sphereBoxHit(sp, inv, oi)) continue;
+        if (!sphereBoxHit(sp, w.inv, w.oi)) continue;
         float dist;
         V3 ni, P;
-        if (rtSphereHit(sp, r, dist, ni, P) && (dist < best_t || (dist == best_t && sp.object < best_obj))) {
-            best_t = dist;
-            best_id = RT_ID_SPHERE | (uint32_t)k;
-            best_obj = sp.object;
+        if (rtSphereHit(sp, w.r, dist, ni, P) && (dist < w.best_t || (dist == w.best_t && w.best_id != RT_ID_MISS && sp.object < w.best_obj))) {
+            w.best_t = dist;
+            w.best_id = RT_ID_SPHERE | (uint32_t)k;
+            w.best_obj = sp.object;
         }
     }
     for (int k = 0; k < sc.n_planes; k++) {
         const RtPlane &pl = an.planes[k];
         float t;
-        if (rtPlaneHit(pl, r, t) && (t < best_t || (t == best_t && pl.object < best_obj))) {
-            best_t = t;
-            best_id = RT_ID_PLANE | (uint32_t)k;
-            best_obj = pl.object;
+        if (rtPlaneHit(pl, w.r, t) && (t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS && pl.object < w.best_obj))) {
+            w.best_t = t;
+            w.best_id = RT_ID_PLANE | (uint32_t)k;
+            w.best_obj = pl.object;
         }
     }
-    traverseBvh<false, STATS>(sc, root_ref, r, inv, oi, best_t, best_id, stack, st);
 }
-
-// is_shadowed() after its back-face test: any object with hit.distance <= dist (main.cpp:50-55)
-template <bool STATS>
-RT_DEV bool occluded(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtRay &r, float dist,
-                     uint32_t *stack, RtTraversalStats &st) {
-    const V3 inv = v3(safeInv(r.d.x), safeInv(r.d.y), safeInv(r.d.z));
-    const V3 oi = v3(r.o.x * inv.x, r.o.y * inv.y, r.o.z * inv.z);
+// is_shadowed() after its back-face test, analytic part: any primitive with hit.distance <= dist (main.cpp:50-55)
+RT_DEV bool analyticOccluded(const RtSceneDev &sc, const RtAnalytic &an, const RtWalk &w, float dist) {
     for (int k = 0; k < sc.n_planes; k++) {
         float t;
-        if (rtPlaneHit(an.planes[k], r, t) && t <= dist) return true;
+        if (rtPlaneHit(an.planes[k], w.r, t) && t <= dist) return true;
     }
     for (int k = 0; k < sc.n_spheres; k++) {
         const RtSphere &sp = an.spheres[k];
-        if (!sphereBoxHit(sp, inv, oi)) continue;
+        if (!sphereBoxHit(sp, w.inv, w.oi)) continue;
         float d;
         V3 ni, P;
-        if (rtSphereHit(sp, r, d, ni, P) && d <= dist) return true;
+        if (rtSphereHit(sp, w.r, d, ni, P) && d <= dist) return true;
     }
-    float tmax = dist;
-    uint32_t id = RT_ID_MISS;
-    return traverseBvh<true, STATS>(sc, root_ref, r, inv, oi, tmax, id, stack, st);
+    return false;
+}
+
+// whole-ray forms (test hook k_hitinfo)
+template <bool SPILL>
+RT_DEV bool occluded(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtRay &r, float dist,
+                     const RtStack &stk, RtTraversalStats &st) {
+    RtWalk w;
+    w.r = r;
+    rtInitWalk(sc, w, root_ref);
+    if (analyticOccluded(sc, an, w, dist)) return true;
+    w.best_t = dist;
+    w.best_id = RT_ID_MISS;
+    w.best_obj = 0;
+    w.best_rank = 0;
+    while (w.cur != RT_NODE_DONE)
+        if (rtStep<true, false, SPILL>(sc, w, stk, st)) return true;
+    return false;
 }
 
 RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st, int nodes_word) {
@@ -270,46 +353,108 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+// Traversal kernels: persistent lanes with dynamic ray fetch.  A wave reserves RT_FETCH_BATCH consecutive queue
+// entries at a time (one returning atomic per batch); a lane whose ray has terminated takes the next entry of the
+// wave's batch instead of idling until the slowest ray of its wave is done.  The walk leaves its loop to refill as
+// soon as fewer than RT_REFILL_BELOW lanes hold a ray.  Ray order does not affect results: hit records go to the
+// ray's own slot and radiance is accumulated in fixed point.
+#define RT_FETCH_BATCH 256u
+#define RT_REFILL_BELOW 48
+
+template <bool ANY, bool STATS, bool SPILL>
+RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
-    uint32_t *stack = s_lds + threadIdx.x;
-    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
+    const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
+    const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);  // +1: dummy row of the branch-free pushes
     const int buf = level & 1;
-    const uint32_t n = min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    const uint32_t n = ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    uint32_t *work = q.counters + (ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
     RtTraversalStats st{0, 0};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        const float4 A = q.rayA[buf][i], B = q.rayB[buf][i];
-        float t = INFINITY;
-        uint32_t id = RT_ID_MISS;
-        if (!(__float_as_uint(B.w) & RT_FLAG_INVALID)) {
-            RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
-            closestHit<STATS>(sc, an, root_ref, r, t, id, stack, st);
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+    bool more = true;                      // wave-uniform: the queue may still hold unclaimed rays
+    bool has = false;
+    uint32_t ray_i = 0, sample = 0;
+    RtWalk w;
+    w.r = RtRay{v3s(0.0f), v3s(0.0f)};
+    w.inv = w.oi = w.err = v3s(0.0f);
+    w.best_t = INFINITY;
+    w.best_id = RT_ID_MISS;
+    w.best_obj = 0x7FFFFFFF;
+    w.best_rank = 0;
+    w.cur = RT_NODE_DONE;
+    w.sp = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!has);
+        if (idle && more) {
+            if (pool_next >= pool_end) {
+                uint32_t base = 0;
+                if (laneId() == 0) base = atomicAdd(work, RT_FETCH_BATCH);
+                base = __builtin_amdgcn_readfirstlane(base);
+                pool_next = min(base, n);
+                pool_end = min(base + RT_FETCH_BATCH, n);
+            }
+            const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(idle);
+            const uint32_t rank = maskRankBelow(idle);
+            if (!has && rank < avail) {
+                ray_i = pool_next + rank;
+                const float4 A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
+                const float4 B = ANY ? q.shB[ray_i] : q.rayB[buf][ray_i];
+                w.r.o = v3(A.x, A.y, A.z);
+                w.r.d = v3(B.x, B.y, B.z);
+                sample = __float_as_uint(B.w);
+                rtInitWalk(sc, w, root_ref);
+                has = true;
+                if (ANY) {
+                    w.best_t = A.w;  // light distance
+                    if (analyticOccluded(sc, an, w, A.w)) has = false;  // occluded: nothing to add
+                } else if (sample & RT_FLAG_INVALID) {  // slot of a pixel outside the image: recorded as a miss
+                    w.best_t = INFINITY;
+                    w.best_id = RT_ID_MISS;
+                    w.cur = RT_NODE_DONE;
+                } else {
+                    analyticClosest(sc, an, w);
+                }
+            }
+            pool_next += min(want, avail);
+            if (pool_next >= pool_end && pool_end >= n) more = false;
         }
-        q.hits[i] = make_float2(t, __uint_as_float(id));
+        if (!__ballot(has)) {
+            if (!more) break;
+            continue;
+        }
+        const int leave_below = more ? RT_REFILL_BELOW : 1;
+        do {
+            if (has) {
+                bool done = w.cur == RT_NODE_DONE;  // no triangles in the scene / invalid slot
+                if (!done) {
+                    if (rtStep<ANY, STATS, SPILL>(sc, w, stk, st)) has = false;  // occluded: the pending radiance is dropped
+                    done = w.cur == RT_NODE_DONE;
+                }
+                if (has && done) {  // walk finished
+                    if (ANY) {
+                        const float4 C = q.shC[ray_i];
+                        unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+                        atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
+                        atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
+                        atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
+                    } else {
+                        q.hits[ray_i] = make_float2(w.best_t, __uint_as_float(w.best_id));
+                    }
+                    has = false;
+                }
+            }
+        } while ((int)__popcll(__ballot(has)) >= leave_below);
     }
-    if (STATS) flushStats(q.counters, st, RT_CNT_NODES);
+    if (STATS) flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
 }
 
-template <bool STATS>
+template <bool STATS, bool SPILL>
+__global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+    traceQueue<false, STATS, SPILL>(sc, root_ref, q, level, stack_entries);
+}
+template <bool STATS, bool SPILL>
 __global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    extern __shared__ uint32_t s_lds[];
-    uint32_t *stack = s_lds + threadIdx.x;
-    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
-    const uint32_t n = min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap);
-    RtTraversalStats st{0, 0};
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
-        const float4 A = q.shA[i], B = q.shB[i];
-        RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
-        if (!occluded<STATS>(sc, an, root_ref, r, A.w, stack, st)) {
-            const float4 C = q.shC[i];
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * __float_as_uint(B.w);
-            atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
-            atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
-            atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
-        }
-    }
-    if (STATS) flushStats(q.counters, st, RT_CNT_ANY_NODES);
+    traceQueue<true, STATS, SPILL>(sc, root_ref, q, level, stack_entries);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -610,8 +755,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_assemble(int width, int height, in
 __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t root_ref, RtQueues q, uint32_t n,
                                                      rt_hit *out_hits, uint8_t *out_shadow, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
-    uint32_t *stack = s_lds + threadIdx.x;
-    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
+    const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
+    const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);  // +1: dummy row of the branch-free pushes
     RtTraversalStats st{0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 A = q.rayA[0][i], B = q.rayB[0][i];
@@ -650,7 +795,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t ro
                     bool s = true;
                     if (!(dot(normal, ld) < 0)) {
                         RtRay sr{h.P + RT_EPSILON * ld, ld};
-                        s = occluded<false>(sc, an, root_ref, sr, dl, stack, st);
+                        s = occluded<true>(sc, an, root_ref, sr, dl, stk, st);
                     }
                     sh[l] = s ? 1 : 0;
                 }
@@ -696,15 +841,25 @@ static inline int gridFor(const RtLaunchCfg &cfg, int blocks_per_cu) { return cf
 void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles) {
     hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles);
 }
+template <bool ANY>
+static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
+    const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
+#define RT_LAUNCH(K, S, P) hipLaunchKernelGGL((K<S, P>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
+    if (ANY) {
+        if (cfg.stack_spills) { if (stats) RT_LAUNCH(k_any, true, true); else RT_LAUNCH(k_any, false, true); }
+        else { if (stats) RT_LAUNCH(k_any, true, false); else RT_LAUNCH(k_any, false, false); }
+    } else {
+        if (cfg.stack_spills) { if (stats) RT_LAUNCH(k_closest, true, true); else RT_LAUNCH(k_closest, false, true); }
+        else { if (stats) RT_LAUNCH(k_closest, true, false); else RT_LAUNCH(k_closest, false, false); }
+    }
+#undef RT_LAUNCH
+}
 void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
-    if (stats) hipLaunchKernelGGL(k_closest<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
-    else hipLaunchKernelGGL(k_closest<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
+    launchTrace<false>(cfg, sc, root_ref, q, level, stats);
 }
 void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
-    if (stats) hipLaunchKernelGGL(k_any<true>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
-    else hipLaunchKernelGGL(k_any<false>, dim3(gridFor(cfg, cfg.trace_blocks_per_cu)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries);
+    launchTrace<true>(cfg, sc, root_ref, q, level, stats);
 }
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles) {
@@ -721,7 +876,7 @@ void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, 
 }
 void rtLaunchHitInfo(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, uint32_t n,
                      rt_hit *out_hits, uint8_t *out_shadow) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     hipLaunchKernelGGL(k_hitinfo, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, n, out_hits, out_shadow, cfg.stack_entries);
 }
 void rtLaunchRaysFromHost(const RtLaunchCfg &cfg, const float *d_rays, uint32_t n, const RtQueues &q) {

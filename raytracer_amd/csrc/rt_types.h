@@ -10,12 +10,14 @@
 #define RT_MAX_LIGHTS 8
 #define RT_MAX_SPHERES 64
 #define RT_MAX_PLANES 64
+#define RT_LDS_STACK_MAX 32      // scenes whose worst-case traversal stack fits this many LDS rows per lane run branch-free
+#define RT_LDS_STACK 16          // otherwise: rows kept in LDS, deeper entries spill to global memory
 #define RT_EPSILON 0.001f       // reference main.cpp:21
 #define RT_ACC_SCALE 4294967296.0   // fixed-point accumulators: 2^32 steps per unit of radiance
 #define RT_ACC_LIMIT 16777216.0f    // contributions are clamped to +-2^24 before conversion
 
-// Linear BVH node, 32 bytes.  Inner: a = index of the left child (the right child is a+1, so a sibling pair is
-// one 64-byte line), b = 0.  Leaf: a = first triangle slot, b = triangle count (1..RT_LEAF_MAX).
+// Binary build node (host only, rt_bvh.cpp): inner a = index of the left child (right = a+1), b = 0; leaf a = first
+// triangle slot, b = triangle count (1..RT_LEAF_MAX).
 struct RtNode {
     float mn[3];
     uint32_t a;
@@ -24,10 +26,34 @@ struct RtNode {
 };
 #define RT_LEAF_MAX 4
 
-// Triangle as the intersection kernel reads it, 48 bytes, BVH (slot) order:
+// 4-wide BVH node as the traversal kernels read it: 64 bytes = one cache line = four 16-byte loads per lane.
+// Child boxes are quantised to 8 bits per plane inside the node's frame: plane = origin + q * scale (scale a power
+// of two, so the product is exact); qlo is rounded down and qhi up, so a decoded box always contains the child's.
+//   q0 = (origin.xyz, scale.x)   q1 = child[0..3]   q2 = (qlo_x, qlo_y, qlo_z, qhi_x)   q3 = (qhi_y, qhi_z, scale.y, scale.z)
+// where every q?? word packs the four children's bytes (child c in byte c).
+// child[c]: 0xFFFFFFFF = empty slot; inner node -> index of the child node; leaf -> RT_NODE_LEAF | (count-1) << 28 |
+// record index of its first triangle.  Nodes and triangle records live in ONE array of 64-byte records (nodes first,
+// then the triangles in leaf order), so a traversal step is the same four loads whether the lane is at a node or
+// at a triangle.
+struct RtNode4 {
+    float origin[3];
+    float scale_x;
+    uint32_t child[4];
+    uint32_t qlo[3];
+    uint32_t qhi_x;
+    uint32_t qhi_y, qhi_z;
+    float scale_y, scale_z;
+};
+#define RT_NODE_LEAF 0x80000000u
+#define RT_NODE_DONE 0xFFFFFFFFu
+#define RT_NODE_INDEX_MASK 0x0FFFFFFFu
+
+// Triangle record, 64 bytes, BVH (slot) order:
 // q0 = (A.xyz, n.x)  q1 = (B.xyz, n.y)  q2 = (C.xyz, n.z); n = normalize(cross(B-A, C-A)) (MeshLoader.h:58)
+// q3 = (object, rank, prim, 0): what the exact-tie rule needs (see RtTriShade)
 struct RtTriGeom {
     float q0[4], q1[4], q2[4];
+    uint32_t object, rank, prim, _pad;
 };
 
 // Per-slot shading attributes, 80 bytes: what Triangle::intersect needs beyond geometry (MeshLoader.h:99-121)
@@ -66,8 +92,8 @@ struct RtLight {
 
 // Everything a kernel needs to see the scene; passed by value (kernarg -> SGPRs).
 struct RtSceneDev {
-    const RtNode *nodes;
-    const RtTriGeom *tri_geom;
+    const RtNode4 *nodes;        // record array: n_nodes nodes, then n_tris triangle records
+    const RtTriGeom *tri_geom;   // = nodes + n_nodes
     const RtTriShade *tri_shade;
     const RtSphere *spheres;
     const RtPlane *planes;
@@ -77,6 +103,7 @@ struct RtSceneDev {
     const uint8_t *bmp[4];
     int32_t bmp_w[4], bmp_h[4], bmp_c[4];
     float ambient[3];
+    float bound;                 // max |coordinate| of any node box (slab-test error bound, rt_kernels.hip)
     int32_t n_nodes, n_tris, n_spheres, n_planes, n_lights, n_objects, n_materials;
 };
 
@@ -114,6 +141,7 @@ struct RtQueues {
     float4 *shA, *shB, *shC;
     long long *accum;          // [chunk samples][3] fixed point
     uint32_t *counters;        // see RtCounter
+    uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
     uint32_t ray_cap, shadow_cap;
 };
 
@@ -128,5 +156,7 @@ struct RtQueues {
 #define RT_CNT_INVALID (35 * RT_CNT_STRIDE)                  // level-0 slots outside the image (ragged edge tiles)
 #define RT_CNT_NODES (36 * RT_CNT_STRIDE)                    // u64 nodes at +0, u64 triangle tests at +2 (closest rays)
 #define RT_CNT_ANY_NODES (37 * RT_CNT_STRIDE)                // same for shadow rays
-#define RT_CNT_WORDS (40 * RT_CNT_STRIDE)
+#define RT_CNT_WORK_CLOSEST(d) ((40 + (d)) * RT_CNT_STRIDE)  // next unclaimed entry of level d's ray queue (dynamic fetch)
+#define RT_CNT_WORK_ANY(d) ((56 + (d)) * RT_CNT_STRIDE)      // same for level d's shadow queue
+#define RT_CNT_WORDS (72 * RT_CNT_STRIDE)
 

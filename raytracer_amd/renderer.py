@@ -122,7 +122,7 @@ class Renderer:
     def get_bvh(self):
         nn, nt = C.c_int64(), C.c_int64()
         self._check(self.lib.rt_get_bvh(self._ctx, C.byref(nn), None, C.byref(nt), None))
-        nodes = np.zeros((nn.value, 8), np.float32)
+        nodes = np.zeros((nn.value, 16), np.uint32)
         order = np.zeros(nt.value, np.uint32)
         self._check(self.lib.rt_get_bvh(self._ctx, C.byref(nn), _p(nodes), C.byref(nt), _p(order)))
         return nodes, order
