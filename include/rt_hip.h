@@ -109,6 +109,11 @@ typedef struct rt_stats {
     uint64_t nodes_visited_any; /* BVH nodes fetched by shadow rays (collect_stats & 1 only) */
     uint64_t tris_tested_any;   /* triangle tests of shadow rays    (collect_stats & 1 only) */
     uint64_t bvh_max_stack;     /* traversal stack entries a ray can need in this BVH */
+    /* collect_stats & 1 only: wave-time breakdown of the traversal kernels in shader clocks, summed over waves:
+     * [0] refill (fetch + ray set-up + result writes), [1] node phases, [2] their count, [3] lanes active in them,
+     * [4] triangle phases, [5] count, [6] lanes, [7] wave lifetime, [8] refills, [9] rays fetched */
+    uint64_t prof_closest[10];
+    uint64_t prof_any[10];
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

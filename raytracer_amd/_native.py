@@ -57,11 +57,11 @@ class Stats(C.Structure):
         ("ms_gen", C.c_double), ("ms_closest", C.c_double), ("ms_shade", C.c_double), ("ms_any", C.c_double),
         ("ms_resolve", C.c_double), ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64),
         ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64), ("n_triangles", C.c_uint64),
-        ("nodes_visited_any", C.c_uint64), ("tris_tested_any", C.c_uint64), ("bvh_max_stack", C.c_uint64),
+        ("nodes_visited_any", C.c_uint64), ("tris_tested_any", C.c_uint64), ("bvh_max_stack", C.c_uint64), ("prof_closest", C.c_uint64 * 10), ("prof_any", C.c_uint64 * 10),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        return {name: (list(getattr(self, name)) if name.startswith("prof_") else getattr(self, name)) for name, _ in self._fields_}
 
 
 class Hit(C.Structure):

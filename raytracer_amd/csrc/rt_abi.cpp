@@ -189,6 +189,10 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
     st->tris_tested += u64at(RT_CNT_NODES + 2);
     st->nodes_visited_any += u64at(RT_CNT_ANY_NODES);
     st->tris_tested_any += u64at(RT_CNT_ANY_NODES + 2);
+    for (int k = 0; k < 10; k++) {
+        st->prof_closest[k] += u64at(RT_CNT_PROF_CLOSEST + 2 * k);
+        st->prof_any[k] += u64at(RT_CNT_PROF_ANY + 2 * k);
+    }
 }
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
@@ -556,15 +560,12 @@ int rt_commit(rt_context *ctx) {
     d.n_lights = (int)ctx->lights.size();
     d.n_objects = n_obj;
     d.n_materials = n_mat;
-    // traversal stack: the worst case (sum of children - 1 along the deepest path) lives in LDS when it fits
-    // RT_LDS_STACK_MAX rows (branch-free kernels); deeper scenes keep RT_LDS_STACK rows in LDS and spill the rest to a
-    // global area per grid thread
-    const bool spills = ctx->bvh.max_stack > RT_LDS_STACK_MAX;
-    const int entries = spills ? RT_LDS_STACK : std::max(1, ctx->bvh.max_stack);
+    // traversal stack: up to RT_LDS_STACK rows per lane in LDS (16 KB per 256-thread block), the rest of the worst case
+    // (sum of children - 1 along the deepest path; rarely reached) in a global spill area per grid thread
+    const int entries = std::max(1, std::min(ctx->bvh.max_stack, RT_LDS_STACK));
     ctx->cfg.stack_entries = entries;
-    ctx->cfg.stack_spills = spills;
     ctx->cfg.analytic_bytes = (int)(ctx->spheres.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
-    const int lds_per_block = (entries + 1) * 256 * 4 + ctx->cfg.analytic_bytes;
+    const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
     const size_t spill_entries = (size_t)std::max(0, ctx->bvh.max_stack - entries);
     if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;

@@ -298,6 +298,28 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
         Collapser c{b.nodes};
         c.out.reserve(b.nodes.size() / 2 + 1);
         c.emit(1, 1, 0);
+        // renumber breadth first: the top levels, which every ray visits, become a prefix of the array (the traversal
+        // kernels stage that prefix in LDS) and siblings stay close
+        {
+            std::vector<uint32_t> bfs, newIndex(c.out.size());
+            bfs.reserve(c.out.size());
+            bfs.push_back(0);
+            for (size_t h = 0; h < bfs.size(); h++)
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t ch = c.out[bfs[h]].child[k];
+                    if (ch != 0xFFFFFFFFu && !(ch & 0x80000000u)) bfs.push_back(ch);
+                }
+            for (size_t i = 0; i < bfs.size(); i++) newIndex[bfs[i]] = (uint32_t)i;
+            std::vector<RtNode4> re(c.out.size());
+            for (size_t i = 0; i < bfs.size(); i++) {
+                re[i] = c.out[bfs[i]];
+                for (int k = 0; k < 4; k++) {
+                    uint32_t &ch = re[i].child[k];
+                    if (ch != 0xFFFFFFFFu && !(ch & 0x80000000u)) ch = newIndex[ch];
+                }
+            }
+            c.out.swap(re);
+        }
         out.nodes = std::move(c.out);
         out.root_ref = 0;
         out.depth = c.maxDepth;

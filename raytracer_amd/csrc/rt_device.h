@@ -364,6 +364,10 @@ RT_DEV float rtToneMap1(float x) {
 RT_DEV long long rtToFixed(float x) {
     if (!(x == x)) return 0;  // NaN contributions are dropped (the reference would poison the pixel)
     x = fminf(fmaxf(x, -RT_ACC_LIMIT), RT_ACC_LIMIT);
-    return __double2ll_rn((double)x * RT_ACC_SCALE);
+    // x = hi + fr exactly (|x| <= 2^24, fr in [0,1)); fr * 2^32 is an integer below 2^32 whenever fr >= 2^-8, and is
+    // truncated to one otherwise: the result is x * 2^32 rounded towards -inf, with float-only arithmetic
+    const float hi = floorf(x), fr = x - hi;
+    // (fr can round up to 1.0f for tiny negative x: clamp below 2^32 so the conversion stays defined)
+    return ((long long)(int)hi << 32) + (long long)(unsigned int)fminf(fr * 4294967296.0f, 4294967040.0f);
 }
 RT_DEV float rtFromFixed(long long a) { return (float)((double)a * (1.0 / RT_ACC_SCALE)); }

@@ -6,8 +6,7 @@
 struct RtLaunchCfg {
     hipStream_t stream = nullptr;
     int num_cus = 256;             // from hipDeviceProp_t at rt_create
-    int stack_entries = 16;        // LDS traversal stack rows per lane (chosen at rt_commit); one dummy row follows them
-    bool stack_spills = false;     // the scene's worst-case stack exceeds the LDS rows: kernels with the global spill path
+    int stack_entries = 16;        // LDS traversal stack rows per lane (chosen at rt_commit); deeper entries spill to global memory
     int analytic_bytes = 0;        // LDS behind the stack holding the staged spheres + planes
     int trace_blocks_per_cu = 4;   // resident 256-thread blocks per CU for the traversal kernels (LDS-limited)
 };

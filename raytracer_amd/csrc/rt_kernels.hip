@@ -61,7 +61,6 @@ RT_DEV RtStack rtMakeStack(uint32_t *lds_base, uint32_t *spill, int lds_entries)
     s.lds_entries = lds_entries;
     return s;
 }
-
 RT_DEV float safeInv(float d) {
     // 1/d with |1/d| capped so that o*inv stays finite (a zero component must not turn the fma into inf-inf)
     float inv = 1.0f / d;
@@ -78,6 +77,7 @@ struct RtWalk {  // per-lane traversal state
     int best_obj;      // object and reference candidate rank of the best hit: the exact-tie rule needs them
     uint32_t best_rank;
     uint32_t cur;      // record reference: node index, RT_NODE_LEAF | (triangles left - 1) << 28 | record index, or DONE
+    uint32_t pend;     // postponed leaf (same encoding) whose triangles are still to be tested, or DONE = none
     int sp;
 };
 
@@ -92,61 +92,57 @@ RT_DEV void rtInitWalk(const RtSceneDev &sc, RtWalk &w, uint32_t root_ref) {
                (fabsf(w.oi.z) + sc.bound * fabsf(w.inv.z)) * u);
     w.sp = 0;
     w.cur = sc.n_tris ? root_ref : RT_NODE_DONE;
+    w.pend = RT_NODE_DONE;
 }
 
 RT_DEV float ubyteF(uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xFFu); }  // v_cvt_f32_ubyte{c}
 
-// One traversal step.  Returns true when an any-hit ray is occluded; otherwise w.cur is the next record or DONE.
-// SPILL = false (the scene's worst-case stack fits the LDS rows): the step is branch-free apart from the node /
-// triangle split -- the stack top is read speculatively together with the record, pushes are three unconditional
-// LDS stores (entries that do not exist go to a dummy row).  SPILL = true keeps conditional pushes / pops that fall
-// through to the global spill area.
-template <bool ANY, bool STATS, bool SPILL>
-RT_DEV bool rtStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTraversalStats &st) {
-    // exactly four 16-byte loads per lane, issued before the node / triangle split; the empty asm pins them as whole
-    // registers (left alone, the compiler re-slices the record into six narrower loads: 50 % more L1 accesses)
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    const v4f *rec = reinterpret_cast<const v4f *>(sc.nodes) + 4 * (size_t)(w.cur & RT_NODE_INDEX_MASK);
-    v4f q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-    uint32_t popped = RT_NODE_DONE;
-    if (!SPILL) {
-        const uint32_t top = stk.lds[(max(w.sp, 1) - 1) * RT_BLOCK];
-        popped = w.sp ? top : RT_NODE_DONE;
-    }
+// A traversal step is split in two so that a wave can run them as separate phases (traceQueue): rtNodeStep tests the
+// four child boxes of the node `cur` refers to, rtTriStep runs the reference's exact test on the next triangle of
+// the postponed leaf `pend`.  Both fetch one 64-byte record with exactly four 16-byte loads per lane; the empty asm
+// pins them as whole registers (left alone, the compiler re-slices the record into six narrower loads: 50 % more L1
+// accesses).  The kernels are VALU bound, so pushes and pops are conditional (skipped work costs only scalar branches).
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define RT_LOAD_RECORD(ref)                                                                                    \
+    const v4f *rec_ = reinterpret_cast<const v4f *>(sc.nodes) + 4 * (size_t)((ref) & RT_NODE_INDEX_MASK);      \
+    v4f q0 = rec_[0], q1 = rec_[1], q2 = rec_[2], q3 = rec_[3];                                                \
     asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
-    if (w.cur & RT_NODE_LEAF) {  // triangle record
-        if (STATS) st.tris++;
-        RtTri T;
-        T.A = v3(q0.x, q0.y, q0.z);
-        T.B = v3(q1.x, q1.y, q1.z);
-        T.C = v3(q2.x, q2.y, q2.z);
-        T.n = v3(q0.w, q1.w, q2.w);
-        float t;
-        if (rtTriHit(T, w.r, w.best_t, t)) {
-            if (ANY) return true;
-            const int obj = (int)__float_as_uint(q3.x);
-            const uint32_t rank = __float_as_uint(q3.y);
-            // strict minimum; on an exact tie the earlier object wins (main.cpp:67) and inside a mesh the earlier
-            // candidate of the reference's order (MeshLoader.h:399-404).  A miss (distance INFINITY) never loses to inf.
-            const bool take = t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
-                                               (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
-            if (take) {
-                w.best_t = t;
-                w.best_id = (w.cur & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes;
-                w.best_obj = obj;
-                w.best_rank = rank;
-            }
+
+// Returns true when an any-hit ray is occluded.  Afterwards w.pend is the leaf's next triangle or RT_NODE_DONE (none).
+template <bool ANY, bool STATS>
+RT_DEV bool rtTriStep(const RtSceneDev &sc, RtWalk &w, RtTraversalStats &st) {
+    RT_LOAD_RECORD(w.pend)
+    if (STATS) st.tris++;
+    RtTri T;
+    T.A = v3(q0.x, q0.y, q0.z);
+    T.B = v3(q1.x, q1.y, q1.z);
+    T.C = v3(q2.x, q2.y, q2.z);
+    T.n = v3(q0.w, q1.w, q2.w);
+    float t;
+    if (rtTriHit(T, w.r, w.best_t, t)) {
+        if (ANY) return true;
+        const int obj = (int)__float_as_uint(q3.x);
+        const uint32_t rank = __float_as_uint(q3.y);
+        // strict minimum; on an exact tie the earlier object wins (main.cpp:67) and inside a mesh the earlier
+        // candidate of the reference's order (MeshLoader.h:399-404).  A miss (distance INFINITY) never loses to inf.
+        const bool take = t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
+                                           (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
+        if (take) {
+            w.best_t = t;
+            w.best_id = (w.pend & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes;
+            w.best_obj = obj;
+            w.best_rank = rank;
         }
-        if ((w.cur >> 28) & 7u) {  // next triangle of the leaf
-            w.cur += 1u - 0x10000000u;
-        } else if (SPILL) {
-            w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
-        } else {
-            w.cur = popped;
-            w.sp = max(w.sp - 1, 0);
-        }
-        return false;
     }
+    if ((w.pend >> 28) & 7u) w.pend += 1u - 0x10000000u;  // next triangle of the leaf
+    else w.pend = RT_NODE_DONE;
+    return false;
+}
+
+// Afterwards w.cur is the nearest hit child (a node or a leaf reference), the next stack entry, or RT_NODE_DONE.
+template <bool ANY, bool STATS>
+RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTraversalStats &st) {
+    RT_LOAD_RECORD(w.cur)
     if (STATS) st.nodes++;
     const V3 m = v3(q0.w * w.inv.x, q3.z * w.inv.y, q3.w * w.inv.z);  // scale / d (scale is a power of two: exact)
     const float ax = __builtin_fmaf(q0.x, w.inv.x, -w.oi.x), ay = __builtin_fmaf(q0.y, w.inv.y, -w.oi.y),
@@ -181,26 +177,22 @@ RT_DEV bool rtStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTraver
     }
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-    if (SPILL) {
-        if (key[0] == 0xFFFFFFFFu) {
-            w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
-        } else {
-            if (key[3] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[3]);
-            if (key[2] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[2]);
-            if (key[1] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[1]);
-            w.cur = ref[0];
-        }
-    } else {
-        // far-first pushes of the hit children 1..n-1: child k goes to entry sp + n-1-k; the rest to the dummy row
-        const int n = (key[0] != 0xFFFFFFFFu) + (key[1] != 0xFFFFFFFFu) + (key[2] != 0xFFFFFFFFu) + (key[3] != 0xFFFFFFFFu);
-        const int top = w.sp + n - 1, dummy = stk.lds_entries;
-        stk.lds[(n > 1 ? top - 1 : dummy) * RT_BLOCK] = ref[1];
-        stk.lds[(n > 2 ? top - 2 : dummy) * RT_BLOCK] = ref[2];
-        stk.lds[(n > 3 ? top - 3 : dummy) * RT_BLOCK] = ref[3];
-        w.cur = n ? ref[0] : popped;
-        w.sp = n ? top : max(w.sp - 1, 0);
+    if (key[0] == 0xFFFFFFFFu) {
+        w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
+    } else {  // descend into the nearest child, push the others far-first
+        if (key[3] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[3]);
+        if (key[2] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[2]);
+        if (key[1] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[1]);
+        w.cur = ref[0];
     }
-    return false;
+}
+
+// moves a leaf reference from cur to the (empty) pend slot and takes the next stack entry
+RT_DEV void rtPostponeLeaf(RtWalk &w, const RtStack &stk) {
+    if (w.pend == RT_NODE_DONE && (w.cur & RT_NODE_LEAF) && w.cur != RT_NODE_DONE) {
+        w.pend = w.cur;
+        w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
+    }
 }
 
 // Analytic primitives are staged once per block into LDS (a few hundred bytes; every lane of every ray reads all of
@@ -272,7 +264,6 @@ RT_DEV bool analyticOccluded(const RtSceneDev &sc, const RtAnalytic &an, const R
 }
 
 // whole-ray forms (test hook k_hitinfo)
-template <bool SPILL>
 RT_DEV bool occluded(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtRay &r, float dist,
                      const RtStack &stk, RtTraversalStats &st) {
     RtWalk w;
@@ -283,9 +274,16 @@ RT_DEV bool occluded(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_r
     w.best_id = RT_ID_MISS;
     w.best_obj = 0;
     w.best_rank = 0;
-    while (w.cur != RT_NODE_DONE)
-        if (rtStep<true, false, SPILL>(sc, w, stk, st)) return true;
-    return false;
+    for (;;) {
+        rtPostponeLeaf(w, stk);
+        if (w.pend != RT_NODE_DONE) {
+            if (rtTriStep<true, false>(sc, w, st)) return true;
+        } else if (w.cur != RT_NODE_DONE) {
+            rtNodeStep<true, false>(sc, w, stk, st);
+        } else {
+            return false;
+        }
+    }
 }
 
 RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st, int nodes_word) {
@@ -361,11 +359,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 #define RT_FETCH_BATCH 256u
 #define RT_REFILL_BELOW 48
 
-template <bool ANY, bool STATS, bool SPILL>
+template <bool ANY, bool STATS>
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
     const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
-    const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);  // +1: dummy row of the branch-free pushes
+    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
     const int buf = level & 1;
     const uint32_t n = ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
     uint32_t *work = q.counters + (ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
@@ -381,10 +379,32 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     w.best_id = RT_ID_MISS;
     w.best_obj = 0x7FFFFFFF;
     w.best_rank = 0;
-    w.cur = RT_NODE_DONE;
+    w.cur = w.pend = RT_NODE_DONE;
     w.sp = 0;
+    // A finished lane parks its result in registers (fin) and writes it when the wave refills, together with the
+    // other lanes that finished meanwhile: written right away, the result code (a load, three fixed-point
+    // conversions and atomics) would run once per ray with one or two lanes active.
+    bool fin = false;
+    auto writeResult = [&]() {
+        if (ANY) {
+            const float4 C = q.shC[ray_i];
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+            atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
+            atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
+            atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
+        } else {
+            q.hits[ray_i] = make_float2(w.best_t, __uint_as_float(w.best_id));
+        }
+        fin = false;
+    };
+    // STATS build only: where a wave's time goes (shader clock): [0] refill cycles, [1] node-phase cycles, [2] node
+    // phases, [3] lanes active in them, [4] triangle-phase cycles, [5] triangle phases, [6] lanes, [7] wave lifetime,
+    // [8] refills, [9] rays fetched
+    unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tStart = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         const unsigned long long idle = __ballot(!has);
+        const unsigned long long tRefill = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
         if (idle && more) {
             if (pool_next >= pool_end) {
                 uint32_t base = 0;
@@ -395,6 +415,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             }
             const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(idle);
             const uint32_t rank = maskRankBelow(idle);
+            if (fin) writeResult();
             if (!has && rank < avail) {
                 ray_i = pool_next + rank;
                 const float4 A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
@@ -417,51 +438,71 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             }
             pool_next += min(want, avail);
             if (pool_next >= pool_end && pool_end >= n) more = false;
+            if (STATS) {
+                prof[0] += __builtin_amdgcn_s_memtime() - tRefill;
+                prof[8]++;
+                prof[9] += min(want, avail);
+            }
         }
         if (!__ballot(has)) {
             if (!more) break;
             continue;
         }
         const int leave_below = more ? RT_REFILL_BELOW : 1;
+        // Phases: a lane that reaches a leaf postpones it (pend) and goes on with its next node; each iteration the
+        // wave runs either a node step or a triangle step, whichever more lanes are ready for, so both bodies run
+        // with most lanes active instead of alternating with partial masks.
         do {
-            if (has) {
-                bool done = w.cur == RT_NODE_DONE;  // no triangles in the scene / invalid slot
-                if (!done) {
-                    if (rtStep<ANY, STATS, SPILL>(sc, w, stk, st)) has = false;  // occluded: the pending radiance is dropped
-                    done = w.cur == RT_NODE_DONE;
+            if (has) rtPostponeLeaf(w, stk);
+            const bool atNode = has && !(w.cur & RT_NODE_LEAF), atTri = has && w.pend != RT_NODE_DONE;
+            const int nNode = (int)__popcll(__ballot(atNode)), nTri = (int)__popcll(__ballot(atTri));
+            const unsigned long long tPhase = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (nNode >= nTri && nNode > 0) {
+                if (atNode) rtNodeStep<ANY, STATS>(sc, w, stk, st);
+                if (STATS) {
+                    prof[1] += __builtin_amdgcn_s_memtime() - tPhase;
+                    prof[2]++;
+                    prof[3] += nNode;
                 }
-                if (has && done) {  // walk finished
-                    if (ANY) {
-                        const float4 C = q.shC[ray_i];
-                        unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
-                        atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
-                        atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
-                        atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
-                    } else {
-                        q.hits[ray_i] = make_float2(w.best_t, __uint_as_float(w.best_id));
-                    }
-                    has = false;
+            } else if (nTri > 0) {
+                if (atTri && rtTriStep<ANY, STATS>(sc, w, st)) has = false;  // occluded: the pending radiance is dropped
+                if (STATS) {
+                    prof[4] += __builtin_amdgcn_s_memtime() - tPhase;
+                    prof[5]++;
+                    prof[6] += nTri;
                 }
+            }
+            if (has && w.cur == RT_NODE_DONE && w.pend == RT_NODE_DONE) {  // walk finished: result written at the next refill
+                fin = true;
+                has = false;
             }
         } while ((int)__popcll(__ballot(has)) >= leave_below);
     }
-    if (STATS) flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
+    if (fin) writeResult();
+    if (STATS) {
+        flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
+        prof[7] = __builtin_amdgcn_s_memtime() - tStart;
+        if (laneId() == 0) {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + (ANY ? RT_CNT_PROF_ANY : RT_CNT_PROF_CLOSEST));
+            for (int k = 0; k < 10; k++) atomicAdd(dst + k, prof[k]);
+        }
+    }
 }
 
-template <bool STATS, bool SPILL>
+template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<false, STATS, SPILL>(sc, root_ref, q, level, stack_entries);
+    traceQueue<false, STATS>(sc, root_ref, q, level, stack_entries);
 }
-template <bool STATS, bool SPILL>
+template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<true, STATS, SPILL>(sc, root_ref, q, level, stack_entries);
+    traceQueue<true, STATS>(sc, root_ref, q, level, stack_entries);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // PhongModel without its nested closest()/is_shadowed() calls (main.cpp:81-213).  One lane per traced ray of
 // `level`; remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
+__global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles) {
     // queue reservation is aggregated per BLOCK: waves post their counts in LDS, one lane per queue does the global
     // atomic (a returning atomic on one address retires every ~10 ns chip-wide, so per-wave reservations of ~40 M
@@ -756,7 +797,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t ro
                                                      rt_hit *out_hits, uint8_t *out_shadow, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
     const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
-    const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);  // +1: dummy row of the branch-free pushes
+    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
     RtTraversalStats st{0, 0};
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
         const float4 A = q.rayA[0][i], B = q.rayB[0][i];
@@ -795,7 +836,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t ro
                     bool s = true;
                     if (!(dot(normal, ld) < 0)) {
                         RtRay sr{h.P + RT_EPSILON * ld, ld};
-                        s = occluded<true>(sc, an, root_ref, sr, dl, stk, st);
+                        s = occluded(sc, an, root_ref, sr, dl, stk, st);
                     }
                     sh[l] = s ? 1 : 0;
                 }
@@ -843,16 +884,11 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 }
 template <bool ANY>
 static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
-    const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
-#define RT_LAUNCH(K, S, P) hipLaunchKernelGGL((K<S, P>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
-    if (ANY) {
-        if (cfg.stack_spills) { if (stats) RT_LAUNCH(k_any, true, true); else RT_LAUNCH(k_any, false, true); }
-        else { if (stats) RT_LAUNCH(k_any, true, false); else RT_LAUNCH(k_any, false, false); }
-    } else {
-        if (cfg.stack_spills) { if (stats) RT_LAUNCH(k_closest, true, true); else RT_LAUNCH(k_closest, false, true); }
-        else { if (stats) RT_LAUNCH(k_closest, true, false); else RT_LAUNCH(k_closest, false, false); }
-    }
+#define RT_LAUNCH(K, S) hipLaunchKernelGGL((K<S>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
+    if (ANY) { if (stats) RT_LAUNCH(k_any, true); else RT_LAUNCH(k_any, false); }
+    else { if (stats) RT_LAUNCH(k_closest, true); else RT_LAUNCH(k_closest, false); }
 #undef RT_LAUNCH
 }
 void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
@@ -876,7 +912,7 @@ void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, 
 }
 void rtLaunchHitInfo(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, uint32_t n,
                      rt_hit *out_hits, uint8_t *out_shadow) {
-    const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     hipLaunchKernelGGL(k_hitinfo, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), lds, cfg.stream, sc, root_ref, q, n, out_hits, out_shadow, cfg.stack_entries);
 }
 void rtLaunchRaysFromHost(const RtLaunchCfg &cfg, const float *d_rays, uint32_t n, const RtQueues &q) {

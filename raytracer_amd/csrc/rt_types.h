@@ -10,8 +10,7 @@
 #define RT_MAX_LIGHTS 8
 #define RT_MAX_SPHERES 64
 #define RT_MAX_PLANES 64
-#define RT_LDS_STACK_MAX 32      // scenes whose worst-case traversal stack fits this many LDS rows per lane run branch-free
-#define RT_LDS_STACK 16          // otherwise: rows kept in LDS, deeper entries spill to global memory
+#define RT_LDS_STACK 16          // traversal stack rows per lane kept in LDS; deeper entries (rare) spill to global memory
 #define RT_EPSILON 0.001f       // reference main.cpp:21
 #define RT_ACC_SCALE 4294967296.0   // fixed-point accumulators: 2^32 steps per unit of radiance
 #define RT_ACC_LIMIT 16777216.0f    // contributions are clamped to +-2^24 before conversion
@@ -156,6 +155,8 @@ struct RtQueues {
 #define RT_CNT_INVALID (35 * RT_CNT_STRIDE)                  // level-0 slots outside the image (ragged edge tiles)
 #define RT_CNT_NODES (36 * RT_CNT_STRIDE)                    // u64 nodes at +0, u64 triangle tests at +2 (closest rays)
 #define RT_CNT_ANY_NODES (37 * RT_CNT_STRIDE)                // same for shadow rays
+#define RT_CNT_PROF_CLOSEST (38 * RT_CNT_STRIDE)             // 10 x u64 wave-time breakdown of k_closest (stats build)
+#define RT_CNT_PROF_ANY (39 * RT_CNT_STRIDE)                 // same for k_any
 #define RT_CNT_WORK_CLOSEST(d) ((40 + (d)) * RT_CNT_STRIDE)  // next unclaimed entry of level d's ray queue (dynamic fetch)
 #define RT_CNT_WORK_ANY(d) ((56 + (d)) * RT_CNT_STRIDE)      // same for level d's shadow queue
 #define RT_CNT_WORDS (72 * RT_CNT_STRIDE)
