@@ -114,6 +114,9 @@ typedef struct rt_stats {
      * [4] triangle phases, [5] count, [6] lanes, [7] wave lifetime, [8] refills, [9] rays fetched */
     uint64_t prof_closest[10];
     uint64_t prof_any[10];
+    /* k_shade: [0] loads + hit reconstruction, [1] material, light culling, textures, ambient, bounce set-up,
+     * [2] queue reservation, [3] shadow-ray emission, [4] next-level emission, [5] wave iterations */
+    uint64_t prof_shade[6];
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

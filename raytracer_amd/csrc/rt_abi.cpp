@@ -193,6 +193,7 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
         st->prof_closest[k] += u64at(RT_CNT_PROF_CLOSEST + 2 * k);
         st->prof_any[k] += u64at(RT_CNT_PROF_ANY + 2 * k);
     }
+    for (int k = 0; k < 6; k++) st->prof_shade[k] += u64at(RT_CNT_PROF_SHADE + 2 * k);
 }
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
@@ -205,7 +206,7 @@ void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, 
             kt.end();
         }
         kt.begin(2);
-        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles);
+        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles, stats);
         kt.end();
         kt.begin(3);
         rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);

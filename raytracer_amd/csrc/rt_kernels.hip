@@ -357,7 +357,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 // soon as fewer than RT_REFILL_BELOW lanes hold a ray.  Ray order does not affect results: hit records go to the
 // ray's own slot and radiance is accumulated in fixed point.
 #define RT_FETCH_BATCH 256u
-#define RT_REFILL_BELOW 48
+#define RT_REFILL_BELOW 24
 
 template <bool ANY, bool STATS>
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries) {
@@ -490,11 +490,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
     traceQueue<false, STATS>(sc, root_ref, q, level, stack_entries);
 }
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
     traceQueue<true, STATS>(sc, root_ref, q, level, stack_entries);
 }
 
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_any(RtSceneDev sc, uint32_t root_r
 // PhongModel without its nested closest()/is_shadowed() calls (main.cpp:81-213).  One lane per traced ray of
 // `level`; remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
+template <bool PROF>
 __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles) {
     // queue reservation is aggregated per BLOCK: waves post their counts in LDS, one lane per queue does the global
@@ -517,6 +518,11 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
     const uint32_t wave = threadIdx.x >> 6, lane = laneId();
     const int nlights = sc.n_lights;
     uint32_t culled = 0, shaded = 0;
+    // PROF build: shader clocks per section, summed over waves: [0] loads + hit reconstruction, [1] material, light
+    // culling, textures, ambient, bounce set-up, [2] queue reservation (barriers + atomics), [3] shadow-ray emission,
+    // [4] next-level emission, [5] iterations
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
+#define RT_PROF_MARK(k) if (PROF) { tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tp; tp = tn; }
     int parity = 0;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < rounded; i += gridDim.x * RT_BLOCK, parity ^= 1) {
         bool active = i < n;
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
             RtFullHit h;
             rtReconstructHit(sc, r, hrec.x, id, h);
+            RT_PROF_MARK(0)
             const rt_material m = sc.materials[h.material];
             P = h.P;
             hT = h.T;
@@ -629,6 +636,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             }
         }
 
+        RT_PROF_MARK(1)
         // ---- block-aggregated reservation of shadow-ray and next-level slots ----
         uint32_t totS = 0;
         for (int l = 0; l < nlights; l++) totS += (uint32_t)__popcll(__ballot((litmask >> l) & 1u));
@@ -652,6 +660,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             offR += s_cnt[parity][1][w];
         }
 
+        RT_PROF_MARK(2)
         // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  Inside the
         // wave's slab the rays are light-major, so a batch of shadow rays towards one light stays coherent for k_any.
         for (int l = 0; l < nlights; l++) {
@@ -696,6 +705,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             }
             offS += (uint32_t)__popcll(mask);
         }
+        RT_PROF_MARK(3)
         // ---- next-level rays, lane-major so that a reflection/refraction pair stays adjacent ----
         {
             uint32_t slot = offR + maskRankBelow(mRefl) + maskRankBelow(mRefr);
@@ -722,7 +732,14 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
                 }
             }
         }
+        RT_PROF_MARK(4)
+        if (PROF) prof[5]++;
     }
+    if (PROF && lane == 0) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + RT_CNT_PROF_SHADE);
+        for (int k = 0; k < 6; k++) atomicAdd(dst + k, prof[k]);
+    }
+#undef RT_PROF_MARK
     // statistics: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) {
         culled += __shfl_down(culled, off);
@@ -898,8 +915,9 @@ void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref
     launchTrace<true>(cfg, sc, root_ref, q, level, stats);
 }
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
-                   uint32_t tile0, uint32_t *primid_tiles) {
-    hipLaunchKernelGGL(k_shade, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles);
+                   uint32_t tile0, uint32_t *primid_tiles, bool prof) {
+    if (prof) hipLaunchKernelGGL(k_shade<true>, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles);
 }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles) {

@@ -159,5 +159,6 @@ struct RtQueues {
 #define RT_CNT_PROF_ANY (39 * RT_CNT_STRIDE)                 // same for k_any
 #define RT_CNT_WORK_CLOSEST(d) ((40 + (d)) * RT_CNT_STRIDE)  // next unclaimed entry of level d's ray queue (dynamic fetch)
 #define RT_CNT_WORK_ANY(d) ((56 + (d)) * RT_CNT_STRIDE)      // same for level d's shadow queue
-#define RT_CNT_WORDS (72 * RT_CNT_STRIDE)
+#define RT_CNT_PROF_SHADE (72 * RT_CNT_STRIDE)               // 6 x u64 wave-time breakdown of k_shade (stats build)
+#define RT_CNT_WORDS (73 * RT_CNT_STRIDE)
 

@@ -17,3 +17,8 @@ for name, rays in (("prof_closest", st["rays_closest"]), ("prof_any", st["rays_s
     print("  node phases %d (%.0f cycles each, %.1f lanes)   tri phases %d (%.0f cycles each, %.1f lanes)" % (p[2], p[1] / max(p[2], 1), p[3] / max(p[2], 1), p[5], p[4] / max(p[5], 1), p[6] / max(p[5], 1)))
     print("  refills %d (%.0f cycles each, %.1f rays each)" % (p[8], p[0] / max(p[8], 1), p[9] / max(p[8], 1)))
     print("  lane-steps per ray: node %.2f tri %.2f" % (p[3] / max(rays, 1), p[6] / max(rays, 1)))
+p = st["prof_shade"]
+tot = sum(p[:5])
+print("prof_shade hits", st["hits_shaded"], "iterations", p[5], "cycles/iteration %.0f" % (tot / max(p[5], 1)))
+for k, name in enumerate(("load+reconstruct", "material/cull/texture/ambient/bounce", "reservation", "shadow emission", "next-level emission")):
+    print("  %-40s %5.1f%%  %.0f cycles/iteration" % (name, 100 * p[k] / tot, p[k] / max(p[5], 1)))
