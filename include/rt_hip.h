@@ -117,6 +117,11 @@ typedef struct rt_stats {
     /* k_shade: [0] loads + hit reconstruction, [1] material, light culling, textures, ambient, bounce set-up,
      * [2] queue reservation, [3] shadow-ray emission, [4] next-level emission, [5] wave iterations */
     uint64_t prof_shade[6];
+    /* packet kernels: [0] packets, [1] node steps, [2] lanes interested in a child, summed over node steps,
+     * [3] triangle steps, [4] live lanes summed over them, [5] packets over the step budget, [6] octant
+     * groups walked, [7] rays handed to the per-lane kernels */
+    uint64_t prof_packet_closest[8];
+    uint64_t prof_packet_any[8];
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,6 +80,8 @@ struct rt_context {
     std::vector<int64_t> mesh_first;  // per object: first global triangle index (or -1)
     DevBuf<RtNode4> d_records;  // BVH nodes, then the triangle records (rt_types.h)
     DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part
+    DevBuf<RtNodeP> d_nodes_p;  // float-box form of the nodes (packet kernels)
+    DevBuf<uint32_t> d_resid;   // queue indices of the rays the packet kernels hand to the per-lane kernels
     DevBuf<RtTriShade> d_shade;
     DevBuf<RtSphere> d_spheres;
     DevBuf<RtPlane> d_planes;
@@ -124,6 +127,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     if (ctx->d_shA.alloc(sh_cap) || ctx->d_shB.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
     if (ctx->d_accum.alloc(samples * 3)) return 1;
     if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
+    if (ctx->d_resid.alloc(sh_cap)) return 1;  // sh_cap >= ray_cap
     ctx->ws_samples = samples;
     ctx->ws_fanout = fo;
     ctx->ws_lights = nl;
@@ -140,6 +144,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     q.accum = ctx->d_accum.p;
     q.counters = ctx->d_counters.p;
     q.spill = ctx->d_spill.p;
+    q.resid = ctx->d_resid.p;
     q.ray_cap = (uint32_t)ray_cap;
     q.shadow_cap = (uint32_t)sh_cap;
     return 0;
@@ -194,6 +199,10 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
         st->prof_any[k] += u64at(RT_CNT_PROF_ANY + 2 * k);
     }
     for (int k = 0; k < 6; k++) st->prof_shade[k] += u64at(RT_CNT_PROF_SHADE + 2 * k);
+    for (int k = 0; k < 8; k++) {
+        st->prof_packet_closest[k] += u64at(RT_CNT_PROF_PACKET_CLOSEST + 2 * k);
+        st->prof_packet_any[k] += u64at(RT_CNT_PROF_PACKET_ANY + 2 * k);
+    }
 }
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
@@ -352,7 +361,7 @@ int rt_destroy(rt_context *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
+    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_nodes_p.release(); ctx->d_resid.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
@@ -532,7 +541,7 @@ int rt_commit(rt_context *ctx) {
         s.rank = rank[t];
         s._pad = 0;
     }
-    if (ctx->d_records.upload(records) || ctx->d_shade.upload(shade)) return 1;
+    if (ctx->d_records.upload(records) || ctx->d_shade.upload(shade) || ctx->d_nodes_p.upload(ctx->bvh.nodes_p)) return 1;
     if (ctx->d_spheres.upload(ctx->spheres) || ctx->d_planes.upload(ctx->planes)) return 1;
     if (ctx->d_materials.upload(ctx->materials) || ctx->d_objmat.upload(ctx->object_material) || ctx->d_lights.upload(ctx->lights)) return 1;
     RtSceneDev &d = ctx->dev;
@@ -547,6 +556,7 @@ int rt_commit(rt_context *ctx) {
     d.nodes = ctx->d_records.p;
     d.tri_geom = reinterpret_cast<const RtTriGeom *>(ctx->d_records.p + nn);
     d.bound = ctx->bvh.bound;
+    d.nodes_p = ctx->d_nodes_p.p;
     d.tri_shade = ctx->d_shade.p;
     d.spheres = ctx->d_spheres.p;
     d.planes = ctx->d_planes.p;
@@ -565,6 +575,11 @@ int rt_commit(rt_context *ctx) {
     // (sum of children - 1 along the deepest path; rarely reached) in a global spill area per grid thread
     const int entries = std::max(1, std::min(ctx->bvh.max_stack, RT_LDS_STACK));
     ctx->cfg.stack_entries = entries;
+    ctx->cfg.packets = nn > 0 && ctx->bvh.max_stack <= 64;  // the packet walk keeps its stack in one VGPR (64 lanes)
+    if (const char *e = getenv("RT_PACKET_LEVELS")) {  // tuning knob: "<closest levels>,<shadow levels>"
+        int a = 1, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2) { ctx->cfg.packet_levels_closest = a; ctx->cfg.packet_levels_any = b; }
+    }
     ctx->cfg.analytic_bytes = (int)(ctx->spheres.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
     const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));

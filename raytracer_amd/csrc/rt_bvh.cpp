@@ -183,6 +183,7 @@ void refOrder(const float *v0, const float *v1, const float *v2, std::vector<uin
 struct Collapser {
     const std::vector<RtNode> &bn;
     std::vector<RtNode4> out;
+    std::vector<RtNodeP> outP;  // same indices as `out`
     int maxDepth = 0, maxStack = 0;
     float bound = 0.0f;
 
@@ -196,6 +197,7 @@ struct Collapser {
     uint32_t emit(uint32_t b, int depth, int pending) {
         const uint32_t self = (uint32_t)out.size();
         out.emplace_back();
+        outP.emplace_back();
         uint32_t kids[4] = {bn[b].a, bn[b].a + 1, 0, 0};
         int nk = 2;
         while (nk < 4) {  // open the inner child with the largest surface
@@ -252,6 +254,15 @@ struct Collapser {
         n.origin[0] = lo[0]; n.origin[1] = lo[1]; n.origin[2] = lo[2];
         n.scale_x = (float)scale[0]; n.scale_y = (float)scale[1]; n.scale_z = (float)scale[2];
         for (int k = 0; k < 4; k++) n.child[k] = child[k];
+        RtNodeP &np = outP[self];
+        std::memset(&np, 0, sizeof np);
+        for (int k = 0; k < 4; k++) {
+            np.child[k] = child[k];
+            for (int a = 0; a < 3; a++) {  // empty slots keep an inverted box (never hit; the reference word says so too)
+                np.lo[a][k] = k < nk ? bn[kids[k]].mn[a] : INFINITY;
+                np.hi[a][k] = k < nk ? bn[kids[k]].mx[a] : -INFINITY;
+            }
+        }
         n.qlo[0] = qlo[0]; n.qlo[1] = qlo[1]; n.qlo[2] = qlo[2];
         n.qhi_x = qhi[0]; n.qhi_y = qhi[1]; n.qhi_z = qhi[2];
         return self;
@@ -262,6 +273,7 @@ struct Collapser {
 
 void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, RtBvh &out) {
     out.nodes.clear();
+    out.nodes_p.clear();
     out.order.clear();
     out.depth = 0;
     out.max_stack = 0;
@@ -311,16 +323,21 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
                 }
             for (size_t i = 0; i < bfs.size(); i++) newIndex[bfs[i]] = (uint32_t)i;
             std::vector<RtNode4> re(c.out.size());
+            std::vector<RtNodeP> reP(c.out.size());
             for (size_t i = 0; i < bfs.size(); i++) {
                 re[i] = c.out[bfs[i]];
+                reP[i] = c.outP[bfs[i]];
                 for (int k = 0; k < 4; k++) {
                     uint32_t &ch = re[i].child[k];
                     if (ch != 0xFFFFFFFFu && !(ch & 0x80000000u)) ch = newIndex[ch];
+                    reP[i].child[k] = ch;
                 }
             }
             c.out.swap(re);
+            c.outP.swap(reP);
         }
         out.nodes = std::move(c.out);
+        out.nodes_p = std::move(c.outP);
         out.root_ref = 0;
         out.depth = c.maxDepth;
         out.max_stack = c.maxStack;
@@ -328,9 +345,12 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     }
     // triangle records follow the nodes in the record array: rebase the leaf references
     const uint32_t base = (uint32_t)out.nodes.size();
-    for (RtNode4 &nd : out.nodes)
-        for (int k = 0; k < 4; k++)
-            if (nd.child[k] != 0xFFFFFFFFu && (nd.child[k] & 0x80000000u)) nd.child[k] += base;
+    for (size_t i = 0; i < out.nodes.size(); i++)
+        for (int k = 0; k < 4; k++) {
+            uint32_t &ch = out.nodes[i].child[k];
+            if (ch != 0xFFFFFFFFu && (ch & 0x80000000u)) ch += base;
+            out.nodes_p[i].child[k] = ch;
+        }
     if (out.root_ref & 0x80000000u) out.root_ref += base;
 }
 

@@ -6,6 +6,7 @@
 
 struct RtBvh {
     std::vector<RtNode4> nodes;   // 4-wide quantised nodes, root = node 0 (rt_types.h: RtNode4)
+    std::vector<RtNodeP> nodes_p; // the same nodes with float child boxes (packet kernels)
     std::vector<uint32_t> order;  // slot -> input triangle index (triangles are re-ordered into leaf order)
     uint32_t root_ref = 0xFFFFFFFFu;  // reference word of the root: node 0, or a leaf when the scene has <= 4 triangles
     int depth = 0;                // maximum depth of the 4-wide tree

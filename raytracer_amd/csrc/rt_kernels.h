@@ -7,6 +7,11 @@ struct RtLaunchCfg {
     hipStream_t stream = nullptr;
     int num_cus = 256;             // from hipDeviceProp_t at rt_create
     int stack_entries = 16;        // LDS traversal stack rows per lane (chosen at rt_commit); deeper entries spill to global memory
+    bool packets = true;           // run the packet kernels first (needs a tree whose worst-case stack fits 64 entries)
+    // levels (from 0) whose closest-hit / shadow queues go through the packet kernels first.  Measured on the
+    // competition scene at 4K/64 spp (profiles/r01_packet_levels.md): only primary rays are coherent enough to pay.
+    int packet_levels_closest = 1;
+    int packet_levels_any = 0;
     int analytic_bytes = 0;        // LDS behind the stack holding the staged spheres + planes
     int trace_blocks_per_cu = 4;   // resident 256-thread blocks per CU for the traversal kernels (LDS-limited)
 };

@@ -359,13 +359,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 #define RT_FETCH_BATCH 256u
 #define RT_REFILL_BELOW 24
 
-template <bool ANY, bool STATS>
+template <bool ANY, bool STATS, bool INDIRECT>
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
     const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
     const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
     const int buf = level & 1;
-    const uint32_t n = ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    // INDIRECT: the rays are those the packet kernel handed over (q.resid holds their queue indices)
+    const uint32_t n = INDIRECT ? q.counters[ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)]
+                                : (ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap));
     uint32_t *work = q.counters + (ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
@@ -417,7 +419,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             const uint32_t rank = maskRankBelow(idle);
             if (fin) writeResult();
             if (!has && rank < avail) {
-                ray_i = pool_next + rank;
+                ray_i = INDIRECT ? q.resid[pool_next + rank] : pool_next + rank;
                 const float4 A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
                 const float4 B = ANY ? q.shB[ray_i] : q.rayB[buf][ray_i];
                 w.r.o = v3(A.x, A.y, A.z);
@@ -489,13 +491,221 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<false, STATS>(sc, root_ref, q, level, stack_entries);
+// ---------------------------------------------------------------------------------------------------------------
+// Packet kernels: 64 queue-consecutive rays (one wave) walk the tree TOGETHER.  At 64 spp a wave's primary rays are
+// the 64 samples of one pixel, its shadow rays leave neighbouring points towards one light: such rays visit nearly
+// the same nodes, so the walk is made wave-uniform -- the node reference, the stack (one VGPR, entry k in lane k) and
+// the order decisions live in scalar registers, nodes and triangles arrive through scalar loads (no L1 traffic, no
+// per-lane stack), and every lane tests the same four boxes / the same triangle with all 64 lanes active.  A child is
+// entered when ANY lane's box test passes, so results are those of the per-lane walk (boxes only cull; the exact
+// triangle test decides).  Packets whose directions do not share one octant, or that exceed a step budget
+// (incoherent rays: the union of their walks is large), are handed to the per-lane kernels through q.resid.
+#define RT_PACKET_BATCH 4u       // packets a wave reserves per atomic
+#define RT_PACKET_BUDGET 160     // node steps after which a packet is declared incoherent
+
+typedef uint32_t u16v __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(4))) u16v *RtScalarRecs;  // constant address space: uniform loads become s_load
+
+template <bool ANY, bool STATS>
+RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtQueues &q, int level,
+                        uint32_t pb, uint32_t n, unsigned long long *prof) {
+    const uint32_t lane = laneId();
+    const int buf = level & 1;
+    const uint32_t i = pb + lane;
+    const bool valid = i < n;
+    RtWalk w;
+    float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f), B = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
+    if (valid) {
+        A = ANY ? q.shA[i] : q.rayA[buf][i];
+        B = ANY ? q.shB[i] : q.rayB[buf][i];
+    }
+    w.r.o = v3(A.x, A.y, A.z);
+    w.r.d = v3(B.x, B.y, B.z);
+    const uint32_t sample = __float_as_uint(B.w);
+    rtInitWalk(sc, w, root_ref);
+    bool alive = valid;
+    if (ANY) {
+        w.best_t = A.w;  // light distance
+        w.best_id = RT_ID_MISS;
+        w.best_obj = 0;
+        w.best_rank = 0;
+        if (alive && analyticOccluded(sc, an, w, A.w)) alive = false;
+    } else {
+        w.best_t = INFINITY;
+        w.best_id = RT_ID_MISS;
+        w.best_obj = 0x7FFFFFFF;
+        w.best_rank = 0;
+        if (sample & RT_FLAG_INVALID) alive = false;  // slot of a pixel outside the image: recorded as a miss
+        if (alive) analyticClosest(sc, an, w);
+    }
+    const unsigned long long am = __ballot(alive);
+    bool toResid = false;
+    // error bound of a plane distance folded into o/d: near planes move towards the origin, far planes away
+    const V3 oiN = w.oi + w.err, oiF = w.oi - w.err;
+    const uint32_t octant = (w.inv.x < 0.0f ? 1u : 0u) | (w.inv.y < 0.0f ? 2u : 0u) | (w.inv.z < 0.0f ? 4u : 0u);
+    const RtScalarRecs nodesP = (RtScalarRecs)(const void *)sc.nodes_p;
+    const RtScalarRecs recs = (RtScalarRecs)(const void *)sc.nodes;
+    int steps = 0;
+    // One walk per direction octant present in the packet (usually one; two where a packet straddles two lights or
+    // mixes reflection and refraction rays): inside a group near / far planes are chosen once, on the scalar unit.
+    for (unsigned long long rem = sc.n_tris ? am : 0ull; rem && !toResid;) {
+        const uint32_t oct = __builtin_amdgcn_readlane(octant, (int)__builtin_ctzll(rem));
+        const bool inGroup = alive && octant == oct;  // alive: shadow rays already found occluded stay out
+        rem &= ~__ballot(octant == oct);
+        if (STATS) prof[6]++;
+        const bool negx = oct & 1u, negy = oct & 2u, negz = oct & 4u;
+        uint32_t cur = __builtin_amdgcn_readfirstlane(root_ref), vstack = 0;
+        int sp = 0;
+        bool act = inGroup;
+        while (cur != RT_NODE_DONE) {
+            if (!(cur & RT_NODE_LEAF)) {
+                if (++steps > RT_PACKET_BUDGET) {
+                    toResid = true;
+                    if (STATS) prof[5]++;
+                    break;
+                }
+                const u16v n0 = nodesP[2 * (size_t)cur], n1 = nodesP[2 * (size_t)cur + 1];
+                unsigned long long m[4];
+                float tnv[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float lx = __uint_as_float(n0[c]), ly = __uint_as_float(n0[4 + c]), lz = __uint_as_float(n0[8 + c]);
+                    const float hx = __uint_as_float(n0[12 + c]), hy = __uint_as_float(n1[c]), hz = __uint_as_float(n1[4 + c]);
+                    const float nx = negx ? hx : lx, fx = negx ? lx : hx;  // uniform selects
+                    const float ny = negy ? hy : ly, fy = negy ? ly : hy;
+                    const float nz = negz ? hz : lz, fz = negz ? lz : hz;
+                    const float tnx = __builtin_fmaf(nx, w.inv.x, -oiN.x), tfx = __builtin_fmaf(fx, w.inv.x, -oiF.x);
+                    const float tny = __builtin_fmaf(ny, w.inv.y, -oiN.y), tfy = __builtin_fmaf(fy, w.inv.y, -oiF.y);
+                    const float tnz = __builtin_fmaf(nz, w.inv.z, -oiN.z), tfz = __builtin_fmaf(fz, w.inv.z, -oiF.z);
+                    const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                    const float tf = fminf(fminf(tfx, tfy), fminf(tfz, w.best_t)) * 1.000001f;
+                    tnv[c] = tn;
+                    m[c] = n1[8 + c] != 0xFFFFFFFFu ? __ballot(act && tn <= tf) : 0ull;
+                }
+                if (STATS) {
+                    prof[1]++;
+                    prof[2] += (unsigned long long)__popcll(m[0] | m[1] | m[2] | m[3]);
+                }
+                // order: entry distance of each child's first interested lane (scalar sort of four pairs)
+                uint32_t key[4], ref[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    ref[c] = n1[8 + c];
+                    key[c] = 0xFFFFFFFFu;
+                    if (m[c]) key[c] = ANY ? (uint32_t)c : __builtin_amdgcn_readlane(__float_as_uint(tnv[c]), (int)__builtin_ctzll(m[c]));
+                }
+#define RT_CSWAP(a, b)                                                  \
+    if (key[b] < key[a]) {                                              \
+        const uint32_t tk = key[a], tr = ref[a];                        \
+        key[a] = key[b]; ref[a] = ref[b]; key[b] = tk; ref[b] = tr;     \
+    }
+                RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                if (key[0] == 0xFFFFFFFFu) {
+                    cur = sp ? __builtin_amdgcn_readlane(vstack, --sp) : RT_NODE_DONE;
+                } else {
+#pragma unroll
+                    for (int c = 3; c >= 1; c--)
+                        if (key[c] != 0xFFFFFFFFu) {
+                            vstack = ((int)lane == sp) ? ref[c] : vstack;
+                            sp++;
+                        }
+                    cur = ref[0];
+                }
+            } else {  // leaf: every live lane of the group runs the exact test on each of its triangles
+                const uint32_t first = cur & RT_NODE_INDEX_MASK, cnt = ((cur >> 28) & 7u) + 1u;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const u16v tr = recs[first + k];
+                    if (STATS) {
+                        prof[3]++;
+                        prof[4] += (unsigned long long)__popcll(__ballot(act));
+                    }
+                    RtTri T;
+                    T.A = v3(__uint_as_float(tr[0]), __uint_as_float(tr[1]), __uint_as_float(tr[2]));
+                    T.B = v3(__uint_as_float(tr[4]), __uint_as_float(tr[5]), __uint_as_float(tr[6]));
+                    T.C = v3(__uint_as_float(tr[8]), __uint_as_float(tr[9]), __uint_as_float(tr[10]));
+                    T.n = v3(__uint_as_float(tr[3]), __uint_as_float(tr[7]), __uint_as_float(tr[11]));
+                    float t;
+                    if (act && rtTriHit(T, w.r, w.best_t, t)) {
+                        if (ANY) {
+                            alive = false;  // occluded: the pending radiance is dropped
+                            act = false;
+                        } else {
+                            const int obj = (int)tr[12];
+                            const uint32_t rank = tr[13];
+                            const bool take = t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
+                                                               (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
+                            if (take) {
+                                w.best_t = t;
+                                w.best_id = first + k - (uint32_t)sc.n_nodes;
+                                w.best_obj = obj;
+                                w.best_rank = rank;
+                            }
+                        }
+                    }
+                }
+                if (ANY && !__ballot(act)) break;  // every ray of the group is occluded
+                cur = sp ? __builtin_amdgcn_readlane(vstack, --sp) : RT_NODE_DONE;
+            }
+        }
+    }
+    if (toResid) {  // hand the packet's live rays to the per-lane kernel (which starts them from scratch)
+        const bool go = ANY ? alive : (valid && !(sample & RT_FLAG_INVALID));  // shadow rays found occluded meanwhile are done
+        const unsigned long long gm = __ballot(go);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(q.counters + (ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)), (uint32_t)__popcll(gm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (go) q.resid[base + maskRankBelow(gm)] = i;
+        if (STATS) prof[7] += (unsigned long long)__popcll(gm);
+        if (!ANY && valid && !go) q.hits[i] = make_float2(INFINITY, __uint_as_float(RT_ID_MISS));
+        return;
+    }
+    if (ANY) {
+        if (alive) {  // unoccluded: the pending radiance of the light arrives
+            const float4 C = q.shC[i];
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+            atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
+            atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
+            atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
+        }
+    } else if (valid) {
+        q.hits[i] = make_float2(w.best_t, __uint_as_float(w.best_id));
+    }
 }
-template <bool STATS>
+
+template <bool ANY, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level) {
+    extern __shared__ uint32_t s_lds[];
+    const RtAnalytic an = stageAnalytic(sc, s_lds);
+    const uint32_t n = ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    uint32_t *work = q.counters + (ANY ? RT_CNT_PWORK_ANY(level) : RT_CNT_PWORK_CLOSEST(level));
+    // STATS: [0] packets, [1] node steps, [2] lanes interested in a child per node step, [3] triangle steps, [4] live
+    // lanes per triangle step, [5] packets over budget, [6] octant groups walked, [7] rays handed to the lane kernel
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (;;) {
+        uint32_t base = 0;
+        if (laneId() == 0) base = atomicAdd(work, 64u * RT_PACKET_BATCH);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t end = min(base + 64u * RT_PACKET_BATCH, n);
+        for (uint32_t pb = base; pb < end; pb += 64u) {
+            if (STATS) prof[0]++;
+            tracePacket<ANY, STATS>(sc, an, root_ref, q, level, pb, n, prof);
+        }
+    }
+    if (STATS && laneId() == 0) {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + (ANY ? RT_CNT_PROF_PACKET_ANY : RT_CNT_PROF_PACKET_CLOSEST));
+        for (int k = 0; k < 8; k++) atomicAdd(dst + k, prof[k]);
+    }
+}
+
+template <bool STATS, bool INDIRECT>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
+    traceQueue<false, STATS, INDIRECT>(sc, root_ref, q, level, stack_entries);
+}
+template <bool STATS, bool INDIRECT>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<true, STATS>(sc, root_ref, q, level, stack_entries);
+    traceQueue<true, STATS, INDIRECT>(sc, root_ref, q, level, stack_entries);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -899,14 +1109,24 @@ static inline int gridFor(const RtLaunchCfg &cfg, int blocks_per_cu) { return cf
 void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles) {
     hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles);
 }
+// packets first (when the tree allows a wave-level stack), then the per-lane kernel over what they handed back
 template <bool ANY>
 static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
     const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
-#define RT_LAUNCH(K, S) hipLaunchKernelGGL((K<S>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
-    if (ANY) { if (stats) RT_LAUNCH(k_any, true); else RT_LAUNCH(k_any, false); }
-    else { if (stats) RT_LAUNCH(k_closest, true); else RT_LAUNCH(k_closest, false); }
+#define RT_LAUNCH(K, S, I) hipLaunchKernelGGL((K<S, I>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
+#define RT_LAUNCHP(A, S) hipLaunchKernelGGL((k_packet<A, S>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, level)
+    if (cfg.packets && level < (ANY ? cfg.packet_levels_any : cfg.packet_levels_closest)) {
+        if (ANY) { if (stats) RT_LAUNCHP(true, true); else RT_LAUNCHP(true, false); }
+        else { if (stats) RT_LAUNCHP(false, true); else RT_LAUNCHP(false, false); }
+        if (ANY) { if (stats) RT_LAUNCH(k_any, true, true); else RT_LAUNCH(k_any, false, true); }
+        else { if (stats) RT_LAUNCH(k_closest, true, true); else RT_LAUNCH(k_closest, false, true); }
+    } else {
+        if (ANY) { if (stats) RT_LAUNCH(k_any, true, false); else RT_LAUNCH(k_any, false, false); }
+        else { if (stats) RT_LAUNCH(k_closest, true, false); else RT_LAUNCH(k_closest, false, false); }
+    }
 #undef RT_LAUNCH
+#undef RT_LAUNCHP
 }
 void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
     launchTrace<false>(cfg, sc, root_ref, q, level, stats);

@@ -43,6 +43,15 @@ struct RtNode4 {
     uint32_t qhi_y, qhi_z;
     float scale_y, scale_z;
 };
+// The same 4-wide tree with full-precision child boxes, 128 bytes per node, same node indices and child references:
+// what the packet kernels read with scalar loads (a whole wave walks one node at a time).
+//   words 0-3 lo.x of children 0..3, 4-7 lo.y, 8-11 lo.z, 12-15 hi.x, 16-19 hi.y, 20-23 hi.z, 24-27 child refs, 28-31 0
+struct RtNodeP {
+    float lo[3][4];
+    float hi[3][4];
+    uint32_t child[4];
+    uint32_t _pad[4];
+};
 #define RT_NODE_LEAF 0x80000000u
 #define RT_NODE_DONE 0xFFFFFFFFu
 #define RT_NODE_INDEX_MASK 0x0FFFFFFFu
@@ -93,6 +102,7 @@ struct RtLight {
 struct RtSceneDev {
     const RtNode4 *nodes;        // record array: n_nodes nodes, then n_tris triangle records
     const RtTriGeom *tri_geom;   // = nodes + n_nodes
+    const RtNodeP *nodes_p;      // packet form of the nodes (float boxes)
     const RtTriShade *tri_shade;
     const RtSphere *spheres;
     const RtPlane *planes;
@@ -141,6 +151,7 @@ struct RtQueues {
     long long *accum;          // [chunk samples][3] fixed point
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
+    uint32_t *resid;           // rays the packet kernels hand to the per-lane kernels (queue indices)
     uint32_t ray_cap, shadow_cap;
 };
 
@@ -160,5 +171,11 @@ struct RtQueues {
 #define RT_CNT_WORK_CLOSEST(d) ((40 + (d)) * RT_CNT_STRIDE)  // next unclaimed entry of level d's ray queue (dynamic fetch)
 #define RT_CNT_WORK_ANY(d) ((56 + (d)) * RT_CNT_STRIDE)      // same for level d's shadow queue
 #define RT_CNT_PROF_SHADE (72 * RT_CNT_STRIDE)               // 6 x u64 wave-time breakdown of k_shade (stats build)
-#define RT_CNT_WORDS (73 * RT_CNT_STRIDE)
+#define RT_CNT_PROF_PACKET_CLOSEST (73 * RT_CNT_STRIDE)      // 8 x u64 packet statistics of k_packet<closest> (stats build)
+#define RT_CNT_PROF_PACKET_ANY (74 * RT_CNT_STRIDE)          // same for shadow packets
+#define RT_CNT_RESID_CLOSEST(d) ((76 + (d)) * RT_CNT_STRIDE) // rays of level d handed to the per-lane closest-hit kernel
+#define RT_CNT_RESID_ANY(d) ((92 + (d)) * RT_CNT_STRIDE)     // same for shadow rays
+#define RT_CNT_PWORK_CLOSEST(d) ((108 + (d)) * RT_CNT_STRIDE) // next unclaimed packet batch of level d (packet kernels)
+#define RT_CNT_PWORK_ANY(d) ((124 + (d)) * RT_CNT_STRIDE)
+#define RT_CNT_WORDS (140 * RT_CNT_STRIDE)
 

@@ -22,3 +22,8 @@ tot = sum(p[:5])
 print("prof_shade hits", st["hits_shaded"], "iterations", p[5], "cycles/iteration %.0f" % (tot / max(p[5], 1)))
 for k, name in enumerate(("load+reconstruct", "material/cull/texture/ambient/bounce", "reservation", "shadow emission", "next-level emission")):
     print("  %-40s %5.1f%%  %.0f cycles/iteration" % (name, 100 * p[k] / tot, p[k] / max(p[5], 1)))
+for name in ("prof_packet_closest", "prof_packet_any"):
+    p = st[name]
+    print(name, "packets", p[0], "node steps/packet %.1f (%.1f lanes interested)" % (p[1] / max(p[0], 1), p[2] / max(p[1], 1)),
+          "tri steps/packet %.1f (%.1f live lanes)" % (p[3] / max(p[0], 1), p[4] / max(p[3], 1)),
+          "over budget %d, octant groups %d, rays to lane kernel %d" % (p[5], p[6], p[7]))
