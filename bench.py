@@ -13,7 +13,7 @@ interleaved over the ranks (tile t -> rank t % N), scene + BVH replicated, one g
 scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
 
 `roofline` is reported for the dominant kernel (k_closest or k_any, whichever took longer): algorithmic bytes
-(32 B per BVH node fetched + 48 B per triangle tested + 56 B per ray, counted in-kernel) over its summed launch time
+(64 B per 4-wide BVH node or triangle record fetched + the ray's queue record, counted in-kernel) over its summed launch time
 measured with HIP events on the launch stream, against 8 TB/s HBM.  The working set of this scene is cache resident,
 so the fraction is expected to be small; `roofline_valu` prices the same kernel against the FP32 vector peak.
 `cpu_baseline` is the compiled reference (oracle/_ref, `g++ -Ofast -fopenmp`) on a bounded sample of the same scene.
@@ -92,29 +92,14 @@ def main():
     scene = FlatScene.builtin(a.scene)
     r = Renderer(local_rank).set_scene(scene)
     W, H = a.width, a.height
-    n_local, n_tiles = r.tile_counts(W, H, rank, world)
-    per = max(r.tile_counts(W, H, k, world)[0] for k in range(world))
-    # tile-major device buffers (torch owns the memory; the renderer writes through raw pointers)
-    t8 = torch.zeros(per, 256, 3, dtype=torch.uint8, device=dev)
-    tp = torch.zeros(per, 256, dtype=torch.int32, device=dev)
-    if rank == 0:
-        g8 = torch.zeros(world, per, 256, 3, dtype=torch.uint8, device=dev)
-        gp = torch.zeros(world, per, 256, dtype=torch.int32, device=dev)
-        o8 = torch.zeros(H, W, 3, dtype=torch.uint8, device=dev)
-        op = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    from raytracer_amd.dist import DistributedFrame, tile_counts
+    n_tiles = tile_counts(W, H, 0, 1)[1]
+    df = DistributedFrame(r, W, H, rank, world, dev, dist)   # tile-major device buffers owned by torch
     stream = torch.cuda.current_stream().cuda_stream
 
     def frame(collect=0):
-        st = r.render_tiles_device(W, H, rank, world, t8.data_ptr(), 0, tp.data_ptr(), stream=stream, spp=a.spp,
-                                   max_depth=a.depth, chunk_samples=a.chunk, collect_stats=collect)
-        if world > 1:  # RCCL gather of the rank-local tile buffers over xGMI, then de-interleave on rank 0
-            dist.gather(t8, list(g8.unbind(0)) if rank == 0 else None, dst=0)
-            dist.gather(tp, list(gp.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                r.assemble_tiles_device(W, H, world, per, g8.data_ptr(), 0, gp.data_ptr(), o8.data_ptr(), 0, op.data_ptr(), stream=stream)
-        elif rank == 0:
-            r.assemble_tiles_device(W, H, 1, per, t8.data_ptr(), 0, tp.data_ptr(), o8.data_ptr(), 0, op.data_ptr(), stream=stream)
-        return st
+        # own tiles -> RCCL gather of the tile-major buffers over xGMI -> de-interleave on rank 0
+        return df.render(stream=stream, spp=a.spp, max_depth=a.depth, chunk_samples=a.chunk, collect_stats=collect)
 
     def sync():
         if world > 1:
@@ -154,25 +139,38 @@ def main():
         }
     if rank == 0 and not a.no_roofline:
         timed = frame(collect=2)       # per-kernel-class HIP-event timing on the launch stream
-        counted = frame(collect=1)     # in-kernel node / triangle counters (slower kernels, counts only)
-        launches = max(timed["launches_closest"], 1)
+        counted = frame(collect=1)     # in-kernel record counters (stats build of the same kernels, counts only)
+        pc, pa = counted["prof_packet_closest"], counted["prof_packet_any"]
+        # 64-byte records fetched: per-lane kernels count one per lane step, packet kernels one 128-byte node (two
+        # records) or one triangle record per WAVE step
         kinds = {
-            "k_closest": (timed["ms_closest"], counted["nodes_visited"], counted["tris_tested"], counted["rays_closest"]),
-            "k_any": (timed["ms_any"], counted["nodes_visited_any"], counted["tris_tested_any"], counted["rays_shadow"]),
+            "k_closest": (timed["ms_closest"], timed["launches_closest"], counted["nodes_visited"] + 2 * pc[1],
+                          counted["tris_tested"] + pc[3], counted["rays_closest"], 40.0),
+            "k_any": (timed["ms_any"], timed["launches_any"], counted["nodes_visited_any"] + 2 * pa[1],
+                      counted["tris_tested_any"] + pa[3], counted["rays_shadow"], 48.0),
         }
         name = max(kinds, key=lambda k: kinds[k][0])
-        ms, nodes, tris, nrays = kinds[name]
-        abytes = 32.0 * nodes + 48.0 * tris + 56.0 * nrays
-        flops = 20.0 * nodes + 80.0 * tris
+        ms, launches, nodes, tris, nrays, ray_bytes = kinds[name]
+        launches = max(launches, 1)
+        abytes = 64.0 * nodes + 64.0 * tris + ray_bytes * nrays   # algorithmic bytes per ray
+        flops = 80.0 * nodes + 80.0 * tris                         # four slab tests per node, SURVEY.md 8(d)
         ach = abytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
+            t = json.load(open(tpath))
+            if t.get("workload") == result["config"]["workload"] and name in t.get("kernels", {}):
+                traffic = t["kernels"][name]["hbm_bytes_per_launch"]
         result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                               "bytes_per_launch": abytes / launches, "avg_launch_ms": ms / launches, "launches": launches,
-                              "nodes_per_ray": nodes / max(nrays, 1), "tris_per_ray": tris / max(nrays, 1)}
+                              "records_per_ray": (nodes + tris) / max(nrays, 1),
+                              "note": "scene records are cache resident: achieved counts algorithmic record fetches, "
+                                      "traffic the HBM side (queues); see roofline_valu for the binding ceiling"}
         tf = flops / (ms / 1e3) / 1e12 if ms > 0 else 0.0
         result["roofline_valu"] = {"kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
-                                   "note": "20 flop per slab test + 80 per triangle test (SURVEY.md 8(d))"}
+                                   "note": "80 flop per 4-wide node (4 slab tests) + 80 per triangle test (SURVEY.md 8(d))"}
         result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
     if rank == 0 and not a.no_cpu and world == 1:
         try:

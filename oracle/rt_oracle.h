@@ -54,11 +54,6 @@ int ro_eval_perlin(int64_t n, const float *p, float *out);
 /* rank[t] = position of triangle t in the order the reference's per-mesh BVH hands candidates out
  * (MeshLoader.h:265-284: left subtree before right, file order inside a leaf), meshes in object order */
 int ro_reference_order(const ro_scene *s, uint32_t *rank);
-/* Walks a linear 32-byte-node BVH (as returned by rt_get_bvh) exactly like the HIP closest-hit kernel does and
- * counts node fetches and triangle tests for the given rays: the in-kernel counters must equal these. */
-int ro_count_traversal(const ro_scene *s, int64_t n_nodes, const float *nodes, const uint32_t *tri_order,
-                       int64_t n, const float *rays, uint64_t *nodes_visited, uint64_t *tris_tested);
-
 #ifdef __cplusplus
 }
 #endif

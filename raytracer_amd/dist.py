@@ -1,0 +1,67 @@
+"""Multi-GPU frames: interleaved 16x16 tiles over ranks, scene + BVH replicated, ONE exchange at frame end.
+
+Tile t of the image belongs to rank t % world (rt_tile_counts / rt_render_tiles_device in include/rt_hip.h); a rank
+renders its tiles into tile-major device buffers; `gather_tiles` moves them to rank 0 with torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests) and rank 0 de-interleaves them with
+rt_assemble_tiles_device.  There is no collective during rendering.  torch is plumbing here (buffers, streams,
+process group), never a compute path.
+"""
+import ctypes as C
+
+from . import _native as N
+
+TILE = 16
+TILE_PIXELS = TILE * TILE
+
+
+def tile_counts(width, height, rank, world):
+    """(tiles owned by `rank`, tiles of the image) -- host arithmetic of the C ABI, needs no GPU"""
+    a, b = C.c_int64(), C.c_int64()
+    if N.hip_lib().rt_tile_counts(width, height, rank, world, C.byref(a), C.byref(b)):
+        raise RuntimeError(N.hip_lib().rt_last_error().decode())
+    return a.value, b.value
+
+
+def tiles_per_rank(width, height, world):
+    """tiles every rank's buffer is padded to (rank 0 owns the most), so that one gather of equal sizes suffices"""
+    return tile_counts(width, height, 0, world)[0]
+
+
+def gather_tiles(local, rank, world, dist=None):
+    """Gathers each rank-local tile-major tensor of `local` to rank 0.
+
+    Returns, on rank 0, a list of tensors shaped [world, *local.shape] (the ranks' buffers back to back in rank order:
+    the layout rt_assemble_tiles_device expects); None elsewhere.  world == 1 needs no process group."""
+    import torch
+    if world == 1:
+        return [t.unsqueeze(0) for t in local]
+    out = []
+    for t in local:
+        g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if rank == 0 else None
+        dist.gather(t, list(g.unbind(0)) if rank == 0 else None, dst=0)
+        out.append(g)
+    return out if rank == 0 else None
+
+
+class DistributedFrame:
+    """One rank's share of a frame on its GPU: render own tiles -> gather -> (rank 0) assemble the image."""
+
+    def __init__(self, renderer, width, height, rank, world, device, dist=None):
+        import torch
+        self.r, self.W, self.H, self.rank, self.world, self.dist = renderer, width, height, rank, world, dist
+        self.per = tiles_per_rank(width, height, world)
+        self.t8 = torch.zeros(self.per, TILE_PIXELS, 3, dtype=torch.uint8, device=device)
+        self.tp = torch.zeros(self.per, TILE_PIXELS, dtype=torch.int32, device=device)
+        if rank == 0:
+            self.o8 = torch.zeros(height, width, 3, dtype=torch.uint8, device=device)
+            self.op = torch.zeros(height, width, dtype=torch.int32, device=device)
+
+    def render(self, stream=0, **kw):
+        """returns this rank's rt_stats dict; on rank 0 self.o8 / self.op hold the assembled image afterwards"""
+        st = self.r.render_tiles_device(self.W, self.H, self.rank, self.world, self.t8.data_ptr(), 0, self.tp.data_ptr(),
+                                        stream=stream, **kw)
+        g = gather_tiles([self.t8, self.tp], self.rank, self.world, self.dist)
+        if self.rank == 0:
+            self.r.assemble_tiles_device(self.W, self.H, self.world, self.per, g[0].data_ptr(), 0, g[1].data_ptr(),
+                                         self.o8.data_ptr(), 0, self.op.data_ptr(), stream=stream)
+        return st
