@@ -167,6 +167,18 @@ RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTr
         const bool hit = tn <= tf && ref[c] != 0xFFFFFFFFu;
         key[c] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;  // tn >= 0: bit order == value order
     }
+    if (ANY) {
+        // any-hit: order is irrelevant to the result -- enter the first hit child, push the others (no sort)
+        uint32_t next = RT_NODE_DONE;
+#pragma unroll
+        for (int c = 3; c >= 0; c--)
+            if (key[c] != 0xFFFFFFFFu) {
+                if (next != RT_NODE_DONE) rtPush(stk, w.sp, next);
+                next = ref[c];
+            }
+        w.cur = next != RT_NODE_DONE ? next : (w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE);
+        return;
+    }
     // sort (entry distance, reference) pairs: 5 comparators
 #define RT_CSWAP(i, j)                                                            \
     {                                                                             \
@@ -387,15 +399,14 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // other lanes that finished meanwhile: written right away, the result code (a load, three fixed-point
     // conversions and atomics) would run once per ray with one or two lanes active.
     bool fin = false;
-    auto writeResult = [&]() {
+    auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
         if (ANY) {
-            const float4 C = q.shC[ray_i];
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
             atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
             atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
         } else {
-            q.hits[ray_i] = make_float2(w.best_t, __uint_as_float(w.best_id));
+            q.hits[ri] = make_float2(w.best_t, __uint_as_float(w.best_id));
         }
         fin = false;
     };
@@ -417,11 +428,18 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             }
             const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(idle);
             const uint32_t rank = maskRankBelow(idle);
-            if (fin) writeResult();
-            if (!has && rank < avail) {
+            // loads first (the new ray's record and, for a finished shadow ray, its pending colour): one round trip
+            const bool take = !has && rank < avail;
+            const uint32_t old_i = ray_i, old_sample = sample;
+            float4 A = make_float4(0, 0, 0, 0), B = A, C = A;
+            if (take) {
                 ray_i = INDIRECT ? q.resid[pool_next + rank] : pool_next + rank;
-                const float4 A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
-                const float4 B = ANY ? q.shB[ray_i] : q.rayB[buf][ray_i];
+                A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
+                B = ANY ? q.shB[ray_i] : q.rayB[buf][ray_i];
+            }
+            if (ANY && fin) C = q.shC[old_i];
+            if (fin) writeResult(old_i, old_sample, C);
+            if (take) {
                 w.r.o = v3(A.x, A.y, A.z);
                 w.r.d = v3(B.x, B.y, B.z);
                 sample = __float_as_uint(B.w);
@@ -480,7 +498,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             }
         } while ((int)__popcll(__ballot(has)) >= leave_below);
     }
-    if (fin) writeResult();
+    if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0));
     if (STATS) {
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
         prof[7] = __builtin_amdgcn_s_memtime() - tStart;
