@@ -93,7 +93,7 @@ struct rt_context {
     // wavefront workspace (sized for one chunk, reused across calls)
     size_t ws_samples = 0;
     int ws_fanout = 0, ws_lights = 0;
-    DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shB, d_shC;
+    DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shC;
     DevBuf<float> d_rayR[2];
     DevBuf<float2> d_hits;
     DevBuf<long long> d_accum;
@@ -124,7 +124,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
         if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
     }
     if (ctx->d_hits.alloc(ray_cap + 1)) return 1;
-    if (ctx->d_shA.alloc(sh_cap) || ctx->d_shB.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
+    if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
     if (ctx->d_accum.alloc(samples * 3)) return 1;
     if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
     if (ctx->d_resid.alloc(sh_cap)) return 1;  // sh_cap >= ray_cap
@@ -139,7 +139,6 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     }
     q.hits = ctx->d_hits.p;
     q.shA = ctx->d_shA.p;
-    q.shB = ctx->d_shB.p;
     q.shC = ctx->d_shC.p;
     q.accum = ctx->d_accum.p;
     q.counters = ctx->d_counters.p;
@@ -288,7 +287,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         const uint32_t tile0 = (uint32_t)(c * chunk_tiles);
         const uint32_t ntiles = (uint32_t)std::min<size_t>(chunk_tiles, (size_t)n_local - tile0);
         HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
-        HIPOK(hipMemsetAsync(ctx->q.accum, 0, (size_t)ntiles * per_tile * 3 * sizeof(long long), stream));
+        // (the sample accumulators need no clearing: level-0 k_shade stores every slot of the chunk)
         kt.begin(0);
         rtLaunchGenPrimary(cfg, f, ctx->q, tile0, ntiles);
         kt.end();
@@ -365,7 +364,7 @@ int rt_destroy(rt_context *ctx) {
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
-    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shB.release(); ctx->d_shC.release(); ctx->d_accum.release();
+    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release();
     ctx->d_counters.release(); ctx->d_chunk_counters.release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -453,7 +452,7 @@ int rt_set_planes(rt_context *ctx, int32_t n, const float *point, const float *n
 }
 
 int rt_set_lights(rt_context *ctx, int32_t n, const float *position, const float *color, const float *ambient) {
-    if (!ctx || n < 0 || n > 32 || (n && (!position || !color))) return fail("rt_set_lights: bad arguments (at most 32 lights)");
+    if (!ctx || n < 0 || n > RT_MAX_LIGHTS || (n && (!position || !color))) return fail("rt_set_lights: bad arguments (at most 16 lights)");
     ctx->lights.resize(n);
     for (int k = 0; k < n; k++) {
         RtLight &l = ctx->lights[k];
@@ -666,7 +665,6 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
         if (rc) break;
         hipError_t e = hipMemcpyAsync(d_rays.p, rays + 6 * off, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice, cfg.stream);
         if (e == hipSuccess) e = hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), cfg.stream);
-        if (e == hipSuccess) e = hipMemsetAsync(ctx->q.accum, 0, (size_t)m * 3 * sizeof(long long), cfg.stream);
         if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
         rtLaunchRaysFromHost(cfg, d_rays.p, m, ctx->q);
         // level 0 closest hit first: the hit records of the batch are reported from it

@@ -371,6 +371,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 #define RT_FETCH_BATCH 256u
 #define RT_REFILL_BELOW 24
 
+// Shadow-queue record -> the Ray of is_shadowed() (main.cpp:49): the record holds the shaded point and the light's
+// index; direction, light distance and the epsilon-offset origin are recomputed with the expressions k_shade uses
+// (same operations, same order => same bits), which keeps the record at 32 bytes instead of 48.
+RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, RtRay &r, float &dist, uint32_t &sample) {
+    const uint32_t wd = __float_as_uint(A.w);
+    sample = wd & RT_SAMPLE_MASK;
+    const V3 P = v3(A.x, A.y, A.z), lp = ld3(sc.lights[wd >> 28].pos);
+    const V3 ld = normalize(lp - P);  // main.cpp:97
+    dist = length(lp - P);            // :98
+    r.o = P + RT_EPSILON * ld;        // :49
+    r.d = ld;
+}
+
 template <bool ANY, bool STATS, bool INDIRECT>
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
@@ -435,19 +448,24 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             if (take) {
                 ray_i = INDIRECT ? q.resid[pool_next + rank] : pool_next + rank;
                 A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
-                B = ANY ? q.shB[ray_i] : q.rayB[buf][ray_i];
+                if (!ANY) B = q.rayB[buf][ray_i];
             }
             if (ANY && fin) C = q.shC[old_i];
             if (fin) writeResult(old_i, old_sample, C);
             if (take) {
-                w.r.o = v3(A.x, A.y, A.z);
-                w.r.d = v3(B.x, B.y, B.z);
-                sample = __float_as_uint(B.w);
+                float ldist = 0.0f;
+                if (ANY) {
+                    rtShadowRay(sc, A, w.r, ldist, sample);
+                } else {
+                    w.r.o = v3(A.x, A.y, A.z);
+                    w.r.d = v3(B.x, B.y, B.z);
+                    sample = __float_as_uint(B.w);
+                }
                 rtInitWalk(sc, w, root_ref);
                 has = true;
                 if (ANY) {
-                    w.best_t = A.w;  // light distance
-                    if (analyticOccluded(sc, an, w, A.w)) has = false;  // occluded: nothing to add
+                    w.best_t = ldist;  // light distance
+                    if (analyticOccluded(sc, an, w, ldist)) has = false;  // occluded: nothing to add
                 } else if (sample & RT_FLAG_INVALID) {  // slot of a pixel outside the image: recorded as a miss
                     w.best_t = INFINITY;
                     w.best_id = RT_ID_MISS;
@@ -535,19 +553,24 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
     float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f), B = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
     if (valid) {
         A = ANY ? q.shA[i] : q.rayA[buf][i];
-        B = ANY ? q.shB[i] : q.rayB[buf][i];
+        if (!ANY) B = q.rayB[buf][i];
     }
-    w.r.o = v3(A.x, A.y, A.z);
-    w.r.d = v3(B.x, B.y, B.z);
-    const uint32_t sample = __float_as_uint(B.w);
+    uint32_t sample = __float_as_uint(B.w);
+    float ldist = 0.0f;
+    if (ANY) {
+        rtShadowRay(sc, A, w.r, ldist, sample);
+    } else {
+        w.r.o = v3(A.x, A.y, A.z);
+        w.r.d = v3(B.x, B.y, B.z);
+    }
     rtInitWalk(sc, w, root_ref);
     bool alive = valid;
     if (ANY) {
-        w.best_t = A.w;  // light distance
+        w.best_t = ldist;  // light distance
         w.best_id = RT_ID_MISS;
         w.best_obj = 0;
         w.best_rank = 0;
-        if (alive && analyticOccluded(sc, an, w, A.w)) alive = false;
+        if (alive && analyticOccluded(sc, an, w, ldist)) alive = false;
     } else {
         w.best_t = INFINITY;
         w.best_id = RT_ID_MISS;
@@ -784,6 +807,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
         bool aniso = false;
         uint32_t litmask = 0;  // bit l: light l faces the surface (is_shadowed's back-face test, main.cpp:44-46)
         bool emitRefl = false, emitRefr = false;
+        V3 amb0 = v3s(0.0f);
         V3 reflDir = v3s(0), refrDir = v3s(0);
         float wRefl = 0, wRefr = 0, fresnelR = 1.0f;
 
@@ -837,10 +861,14 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             if (m.has_img_texture) amb = ld3(sc.ambient) * 0.1f * rtEvalTexture(sc, m.occlusion, h.uv).x;
             else amb = ld3(sc.ambient) * ld3(m.ambient);
             amb = amb * weight;
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
-            atomicAdd(acc + 0, (unsigned long long)rtToFixed(amb.x));
-            atomicAdd(acc + 1, (unsigned long long)rtToFixed(amb.y));
-            atomicAdd(acc + 2, (unsigned long long)rtToFixed(amb.z));
+            if (level == 0) {  // first contribution of the sample: stored below, together with the zeros of the misses
+                amb0 = amb;
+            } else {
+                unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+                atomicAdd(acc + 0, (unsigned long long)rtToFixed(amb.x));
+                atomicAdd(acc + 1, (unsigned long long)rtToFixed(amb.y));
+                atomicAdd(acc + 2, (unsigned long long)rtToFixed(amb.z));
+            }
 
             if (hasRefl) {  // main.cpp:152-166
                 reflDir = rtReflect(-view, ns);
@@ -864,6 +892,14 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             }
         }
 
+        if (level == 0 && i < n) {
+            // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
+            // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.
+            long long *acc = q.accum + 3ull * sample;
+            acc[0] = rtToFixed(amb0.x);
+            acc[1] = rtToFixed(amb0.y);
+            acc[2] = rtToFixed(amb0.z);
+        }
         RT_PROF_MARK(1)
         // ---- block-aggregated reservation of shadow-ray and next-level slots ----
         uint32_t totS = 0;
@@ -922,10 +958,8 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
                 c = c * directScale2;
                 c = c * weight;
                 const uint32_t slot = offS + maskRankBelow(mask);
-                if (slot < q.shadow_cap) {
-                    const V3 so = P + RT_EPSILON * ld;  // main.cpp:49
-                    q.shA[slot] = make_float4(so.x, so.y, so.z, dl);
-                    q.shB[slot] = make_float4(ld.x, ld.y, ld.z, __uint_as_float(sample));
+                if (slot < q.shadow_cap) {  // 32-byte record: point + (sample, light), pending colour (rtShadowRay rebuilds the ray)
+                    q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | ((uint32_t)l << 28)));
                     q.shC[slot] = make_float4(c.x, c.y, c.z, 0.0f);
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);

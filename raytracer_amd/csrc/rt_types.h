@@ -7,7 +7,7 @@
 
 #define RT_TILE 16              // image tile edge, reference main.cpp:565
 #define RT_TILE_PIXELS 256
-#define RT_MAX_LIGHTS 8
+#define RT_MAX_LIGHTS 16         // the light index shares a word with the 28-bit sample index in the shadow queue
 #define RT_MAX_SPHERES 64
 #define RT_MAX_PLANES 64
 #define RT_LDS_STACK 16          // traversal stack rows per lane kept in LDS; deeper entries (rare) spill to global memory
@@ -140,14 +140,14 @@ struct RtFrameDev {
 #define RT_FLAG_INVALID 0x20000000u           // level-0 slot of a pixel outside the image: traced as a miss, never shaded
 
 // Wavefront queues of one chunk (device pointers).  Rays: A = (origin.xyz, weight), B = (direction.xyz, sample|flags),
-// R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (origin.xyz, light distance),
-// B = (direction.xyz, sample), C = (pending rgb, 0).
+// R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (shaded point, sample | light << 28),
+// C = (pending rgb, 0); origin, direction and light distance are recomputed from the point (rtShadowRay).
 struct RtQueues {
     float4 *rayA[2];
     float4 *rayB[2];
     float *rayR[2];
     float2 *hits;
-    float4 *shA, *shB, *shC;
+    float4 *shA, *shC;
     long long *accum;          // [chunk samples][3] fixed point
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
