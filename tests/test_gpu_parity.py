@@ -154,3 +154,22 @@ def test_empty_and_error_paths():
     # a ray that leaves the scene: black, miss record
     col, hits, sh, st = renderer_for("competition").trace_batch(np.array([[0, 50, 0, 0, 1, 0]], np.float32))
     assert hits["hit"][0] == 0 and hits["prim"][0] == N.PRIM_MISS and np.all(col == 0)
+
+
+def test_stress_lattice_against_oracle(oracle_for):
+    """SURVEY.md 8(d) C5 in small: the competition meshes replicated on a lattice (here 9 replicas, 614 k triangles;
+    synthetic, no reference counterpart, so the checker is the pinned oracle).  Exercises a deeper tree: stack rows
+    beyond the LDS part, and -- when the worst-case stack exceeds 64 -- the path without packet kernels."""
+    name = "stress:9"
+    r = renderer_for(name)
+    w, h = 128, 96
+    gpu = r.render(w, h, spp=4)
+    cpu = oracle_for(name, lazy=False).render(w, h, spp=4)
+    ids = (gpu["primid"] == cpu["primid"]).mean()
+    frac, psnr = image_metrics(gpu["rgb8"], cpu["rgb8"])
+    st = gpu["stats"]
+    print(f"{name}: {st['n_triangles']} triangles, {st['bvh_nodes']} nodes, depth {st['bvh_depth']}, max stack {st['bvh_max_stack']}; "
+          f"primid {ids:.6f} rgb8<=1 {frac:.6f} psnr {psnr:.2f} dB")
+    assert st["n_triangles"] == 9 * 68202
+    assert ids >= 0.9999 and frac >= 0.999 and psnr >= 50.0
+    assert st["queue_overflow"] == 0
