@@ -228,6 +228,13 @@ int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out);
  * BVH slot i.  Pass NULL to query sizes only. */
 int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order);
 
+/* Host-only self check of the BVH builder (no GPU, no context; used by the CPU tests): builds the tree of the given
+ * triangles with `threads` host threads (0 = default), returns the node count, a hash of nodes + triangle order (equal
+ * for every thread count) and the number of containment violations (a triangle outside a box above it, a quantised
+ * box smaller than its float box, a triangle not reached exactly once) -- which must be 0.  No reference counterpart. */
+int rt_bvh_check(int64_t n, const float *v0, const float *v1, const float *v2, int32_t threads, int64_t *n_nodes,
+                 uint64_t *hash, int64_t *violations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -739,6 +739,73 @@ int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out) {
     return rc;
 }
 
+int rt_bvh_check(int64_t n, const float *v0, const float *v1, const float *v2, int32_t threads, int64_t *n_nodes,
+                 uint64_t *hash, int64_t *violations) {
+    if (n < 0 || (n && (!v0 || !v1 || !v2))) return fail("rt_bvh_check: bad arguments");
+    if (threads > 0) setenv("RT_BUILD_THREADS", std::to_string(threads).c_str(), 1);
+    RtBvh bvh;
+    rtBuildBvh(n, v0, v1, v2, bvh);
+    if (threads > 0) unsetenv("RT_BUILD_THREADS");
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t bytes) {
+        const uint8_t *b = (const uint8_t *)p;
+        for (size_t k = 0; k < bytes; k++) h = (h ^ b[k]) * 1099511628211ull;
+    };
+    mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode4));
+    mix(bvh.nodes_p.data(), bvh.nodes_p.size() * sizeof(RtNodeP));
+    mix(bvh.order.data(), bvh.order.size() * sizeof(uint32_t));
+    // containment: walking down from the root, every triangle must lie inside the decoded (quantised) box and the
+    // float box of every child slot above it, and every triangle must be reached exactly once
+    int64_t bad = 0;
+    std::vector<uint8_t> seen((size_t)n, 0);
+    const uint32_t nn = (uint32_t)bvh.nodes.size();
+    struct Item { uint32_t ref; float lo[3], hi[3]; };
+    std::vector<Item> stack;
+    Item root{bvh.root_ref, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+    if (n) stack.push_back(root);
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.ref & 0x80000000u) {
+            const uint32_t first = (it.ref & 0x0FFFFFFFu) - nn, cnt = ((it.ref >> 28) & 7u) + 1u;
+            for (uint32_t s = first; s < first + cnt; s++) {
+                if (s >= (uint32_t)n) { bad++; continue; }
+                const uint32_t t = bvh.order[s];
+                seen[t]++;
+                const float *vs[3] = {v0 + 3 * (size_t)t, v1 + 3 * (size_t)t, v2 + 3 * (size_t)t};
+                for (int v = 0; v < 3; v++)
+                    for (int ax = 0; ax < 3; ax++)
+                        if (vs[v][ax] < it.lo[ax] || vs[v][ax] > it.hi[ax]) bad++;
+            }
+            continue;
+        }
+        const RtNode4 &nd = bvh.nodes[it.ref];
+        const RtNodeP &np = bvh.nodes_p[it.ref];
+        const double sc[3] = {nd.scale_x, nd.scale_y, nd.scale_z};
+        const uint32_t qhi[3] = {nd.qhi_x, nd.qhi_y, nd.qhi_z};
+        for (int k = 0; k < 4; k++) {
+            if (nd.child[k] == 0xFFFFFFFFu) continue;
+            if (np.child[k] != nd.child[k]) bad++;
+            Item c;
+            c.ref = nd.child[k];
+            for (int ax = 0; ax < 3; ax++) {  // intersection of the ancestors' boxes with this slot's two boxes
+                const double qlo = nd.origin[ax] + ((nd.qlo[ax] >> (8 * k)) & 255u) * sc[ax];
+                const double qh = nd.origin[ax] + ((qhi[ax] >> (8 * k)) & 255u) * sc[ax];
+                if (qlo > np.lo[ax][k] || qh < np.hi[ax][k]) bad++;  // the quantised box must contain the float box
+                c.lo[ax] = std::fmax(it.lo[ax], np.lo[ax][k]);
+                c.hi[ax] = std::fmin(it.hi[ax], np.hi[ax][k]);
+            }
+            stack.push_back(c);
+        }
+    }
+    for (int64_t t = 0; t < n; t++)
+        if (seen[t] != 1) bad++;
+    if (n_nodes) *n_nodes = (int64_t)bvh.nodes.size();
+    if (hash) *hash = h;
+    if (violations) *violations = bad;
+    return 0;
+}
+
 int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order) {
     if (!ctx || !ctx->committed) return fail("rt_get_bvh: no committed scene");
     if (n_nodes) *n_nodes = (int64_t)ctx->bvh.nodes.size();

@@ -15,7 +15,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
+#include <thread>
 
 namespace {
 
@@ -42,13 +47,46 @@ struct Box {
 
 constexpr int kBins = 16;
 
+// Host threads of the build (the 50 M-triangle scene).  RT_BUILD_THREADS overrides; OMP_NUM_THREADS
+// is honoured because the GPU boxes set it to their CPU share.
+int buildThreads() {
+    for (const char *name : {"RT_BUILD_THREADS", "OMP_NUM_THREADS"})
+        if (const char *e = std::getenv(name)) {
+            const int v = std::atoi(e);
+            if (v > 0) return std::min(v, 64);
+        }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::min(std::max(hw, 1u), 16u);
+}
+
+// fn(tid, begin, end) over [lo, hi) split into contiguous pieces, one thread each
+template <class F>
+void parallelRange(size_t lo, size_t hi, int threads, F fn) {
+    const size_t n = hi - lo;
+    threads = (int)std::min<size_t>((size_t)std::max(threads, 1), std::max<size_t>(n / 65536, 1));
+    if (threads <= 1) return fn(0, lo, hi);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++)
+        pool.emplace_back([=, &fn] { fn(t, lo + n * t / threads, lo + n * (t + 1) / threads); });
+    for (std::thread &th : pool) th.join();
+}
+
+double nowSeconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct BuildTask { uint32_t self, lo, hi; int depth; };
+
+// One builder = one node array.  The scene-level builder walks the top of the tree (its big nodes bin in parallel)
+// and, below `cutoff` triangles, defers subtrees as tasks; worker threads build those into private node arrays that
+// are appended afterwards (disjoint ranges of `index`, so the partitioning needs no locks).
 struct Builder {
-    const float *v0, *v1, *v2;
-    std::vector<Box> triBox;
-    std::vector<float> centroid;  // 3 per triangle
-    std::vector<uint32_t> index;  // permutation being partitioned
+    const Box *triBox = nullptr;
+    const float *centroid = nullptr;  // 3 per triangle
+    uint32_t *index = nullptr;        // permutation being partitioned
     std::vector<RtNode> nodes;
     int maxDepth = 0;
+    uint32_t cutoff = 0;              // 0: build everything here
+    int threads = 1;
+    std::vector<BuildTask> tasks;
 
     void setNodeBox(RtNode &n, const Box &b) {
         // pad: the slab test in the kernel uses fma(mn, 1/d, -o/d); its rounding scales with |coordinate|
@@ -61,14 +99,31 @@ struct Builder {
 
     // builds the subtree of triangles index[lo, hi) into node `self`
     void build(uint32_t self, uint32_t lo, uint32_t hi, int depth) {
+        const uint32_t count = hi - lo;
+        if (cutoff && count <= cutoff) {
+            tasks.push_back(BuildTask{self, lo, hi, depth});
+            return;
+        }
         maxDepth = std::max(maxDepth, depth);
+        const int nt = count >= (1u << 20) ? threads : 1;  // only the few huge nodes at the top are worth threads
         Box box, cbox;
-        for (uint32_t i = lo; i < hi; i++) {
-            box.grow(triBox[index[i]]);
-            cbox.grow(&centroid[3 * (size_t)index[i]]);
+        {
+            std::vector<Box> pb(nt), pc(nt);
+            parallelRange(lo, hi, nt, [&](int t, size_t a, size_t e) {
+                Box b1, c1;
+                for (size_t i = a; i < e; i++) {
+                    b1.grow(triBox[index[i]]);
+                    c1.grow(&centroid[3 * (size_t)index[i]]);
+                }
+                pb[t] = b1;
+                pc[t] = c1;
+            });
+            for (int t = 0; t < nt; t++) {
+                box.grow(pb[t]);
+                cbox.grow(pc[t]);
+            }
         }
         setNodeBox(nodes[self], box);
-        const uint32_t count = hi - lo;
         auto makeLeaf = [&]() {
             nodes[self].a = lo;
             nodes[self].b = count;
@@ -84,12 +139,25 @@ struct Builder {
             Box bins[kBins];
             uint32_t cnt[kBins] = {0};
             const float scale = kBins / cext;
-            for (uint32_t i = lo; i < hi; i++) {
-                const uint32_t t = index[i];
-                int b = (int)((centroid[3 * (size_t)t + axis] - cmin) * scale);
-                b = std::min(std::max(b, 0), kBins - 1);
-                bins[b].grow(triBox[t]);
-                cnt[b]++;
+            {
+                struct Part { Box bins[kBins]; uint32_t cnt[kBins]; };
+                std::vector<Part> part(nt);
+                parallelRange(lo, hi, nt, [&](int tid, size_t a, size_t e) {
+                    Part &p = part[tid];
+                    for (int b = 0; b < kBins; b++) p.cnt[b] = 0;
+                    for (size_t i = a; i < e; i++) {
+                        const uint32_t t = index[i];
+                        int b = (int)((centroid[3 * (size_t)t + axis] - cmin) * scale);
+                        b = std::min(std::max(b, 0), kBins - 1);
+                        p.bins[b].grow(triBox[t]);
+                        p.cnt[b]++;
+                    }
+                });
+                for (int tid = 0; tid < nt; tid++)
+                    for (int b = 0; b < kBins; b++) {
+                        bins[b].grow(part[tid].bins[b]);
+                        cnt[b] += part[tid].cnt[b];
+                    }
             }
             float rightArea[kBins];
             uint32_t rightCnt[kBins];
@@ -123,12 +191,12 @@ struct Builder {
         uint32_t mid;
         if (bestAxis >= 0) {
             const float cmin = cbox.mn[bestAxis], scale = kBins / (cbox.mx[bestAxis] - cbox.mn[bestAxis]);
-            auto it = std::partition(index.begin() + lo, index.begin() + hi, [&](uint32_t t) {
+            auto it = std::partition(index + lo, index + hi, [&](uint32_t t) {
                 int b = (int)((centroid[3 * (size_t)t + bestAxis] - cmin) * scale);
                 b = std::min(std::max(b, 0), kBins - 1);
                 return b <= bestSplit;
             });
-            mid = (uint32_t)(it - index.begin());
+            mid = (uint32_t)(it - index);
         } else {
             mid = lo;  // all centroids coincide
         }
@@ -139,7 +207,7 @@ struct Builder {
         if (depth >= 40 && bestAxis >= 0) {
             const int axis = bestAxis;
             mid = lo + count / 2;
-            std::nth_element(index.begin() + lo, index.begin() + mid, index.begin() + hi, [&](uint32_t a, uint32_t b) {
+            std::nth_element(index + lo, index + mid, index + hi, [&](uint32_t a, uint32_t b) {
                 return centroid[3 * (size_t)a + axis] < centroid[3 * (size_t)b + axis];
             });
         }
@@ -281,24 +349,64 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     out.binary_nodes = 0;
     out.root_ref = 0xFFFFFFFFu;
     if (n <= 0) return;
+    const bool verbose = std::getenv("RT_VERBOSE") != nullptr;
+    const double t0 = nowSeconds();
+    const int threads = buildThreads();
+    std::vector<Box> triBox((size_t)n);
+    std::vector<float> centroid(3 * (size_t)n);
+    std::vector<uint32_t> index((size_t)n);
+    parallelRange(0, (size_t)n, threads, [&](int, size_t a, size_t e) {
+        for (size_t t = a; t < e; t++) {
+            Box &bx = triBox[t];
+            bx.grow(v0 + 3 * t);
+            bx.grow(v1 + 3 * t);
+            bx.grow(v2 + 3 * t);
+            for (int k = 0; k < 3; k++) centroid[3 * t + k] = 0.5f * (bx.mn[k] + bx.mx[k]);
+            index[t] = (uint32_t)t;
+        }
+    });
     Builder b;
-    b.v0 = v0; b.v1 = v1; b.v2 = v2;
-    b.triBox.resize(n);
-    b.centroid.resize(3 * (size_t)n);
-    b.index.resize(n);
-    std::iota(b.index.begin(), b.index.end(), 0u);
-    for (int64_t t = 0; t < n; t++) {
-        Box &bx = b.triBox[t];
-        bx.grow(v0 + 3 * t);
-        bx.grow(v1 + 3 * t);
-        bx.grow(v2 + 3 * t);
-        for (int k = 0; k < 3; k++) b.centroid[3 * t + k] = 0.5f * (bx.mn[k] + bx.mx[k]);
-    }
+    b.triBox = triBox.data();
+    b.centroid = centroid.data();
+    b.index = index.data();
+    b.threads = threads;
+    b.cutoff = (threads > 1 && n >= (1 << 18)) ? (uint32_t)std::max<int64_t>(n / (16 * (int64_t)threads), 4096) : 0u;
     b.nodes.reserve(2 * (size_t)n + 2);
-    b.nodes.resize(2);  // [0] padding so that sibling pairs start at even indices, [1] root
+    b.nodes.resize(2);  // [0] unused, [1] root
     std::memset(b.nodes.data(), 0, 2 * sizeof(RtNode));
     b.build(1, 0, (uint32_t)n, 0);
-    out.order = std::move(b.index);
+    const double t1 = nowSeconds();
+    if (!b.tasks.empty()) {  // subtrees in parallel, each into a private node array ([0] = the subtree's root)
+        std::vector<Builder> sub(b.tasks.size());
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&] {
+                for (size_t k; (k = next.fetch_add(1)) < b.tasks.size();) {
+                    Builder &w = sub[k];
+                    w.triBox = b.triBox;
+                    w.centroid = b.centroid;
+                    w.index = b.index;
+                    w.nodes.resize(1);
+                    std::memset(w.nodes.data(), 0, sizeof(RtNode));
+                    w.build(0, b.tasks[k].lo, b.tasks[k].hi, b.tasks[k].depth);
+                }
+            });
+        for (std::thread &th : pool) th.join();
+        for (size_t k = 0; k < sub.size(); k++) {  // append: local node j >= 1 becomes global node base + j - 1
+            const uint32_t base = (uint32_t)b.nodes.size();
+            auto fix = [&](RtNode nd) {
+                if (nd.b == 0) nd.a += base - 1;
+                return nd;
+            };
+            b.nodes[b.tasks[k].self] = fix(sub[k].nodes[0]);
+            for (size_t j = 1; j < sub[k].nodes.size(); j++) b.nodes.push_back(fix(sub[k].nodes[j]));
+            b.maxDepth = std::max(b.maxDepth, sub[k].maxDepth);
+            std::vector<RtNode>().swap(sub[k].nodes);
+        }
+    }
+    const double t2 = nowSeconds();
+    out.order = std::move(index);
     out.binary_nodes = (int64_t)b.nodes.size();
     const RtNode &root = b.nodes[1];
     if (root.b) {  // the whole scene is one leaf
@@ -352,18 +460,33 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
             out.nodes_p[i].child[k] = ch;
         }
     if (out.root_ref & 0x80000000u) out.root_ref += base;
+    if (verbose)
+        std::fprintf(stderr, "[rt_bvh] %lld triangles, %d threads: top %.2f s, subtrees %.2f s (%zu tasks), collapse+quantise+renumber %.2f s\n",
+                     (long long)n, threads, t1 - t0, t2 - t1, b.tasks.size(), nowSeconds() - t2);
 }
 
 void rtReferenceOrder(int64_t n, const float *v0, const float *v1, const float *v2, const int32_t *object_id,
                       uint32_t *rank) {
-    uint32_t next = 0;
-    int64_t k = 0;
-    while (k < n) {
+    // meshes are independent: the ranks of mesh m are first(m) .. first(m) + count(m) - 1
+    std::vector<std::pair<int64_t, int64_t>> meshes;
+    for (int64_t k = 0; k < n;) {
         int64_t e = k;
         while (e < n && object_id[e] == object_id[k]) e++;
-        std::vector<uint32_t> mesh((size_t)(e - k));
-        std::iota(mesh.begin(), mesh.end(), (uint32_t)k);
-        refOrder(v0, v1, v2, mesh, 0, 0, next, rank);
+        meshes.emplace_back(k, e);
         k = e;
     }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t m; (m = next.fetch_add(1)) < meshes.size();) {
+            std::vector<uint32_t> mesh((size_t)(meshes[m].second - meshes[m].first));
+            std::iota(mesh.begin(), mesh.end(), (uint32_t)meshes[m].first);
+            uint32_t r = (uint32_t)meshes[m].first;
+            refOrder(v0, v1, v2, mesh, 0, 0, r, rank);
+        }
+    };
+    const int threads = n >= (1 << 18) ? buildThreads() : 1;
+    if (threads <= 1) return work();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(work);
+    for (std::thread &th : pool) th.join();
 }
