@@ -171,6 +171,11 @@ int rt_set_triangles(rt_context *ctx, int64_t n, const float *v0, const float *v
 int rt_set_spheres(rt_context *ctx, int32_t n, const float *M, const float *Minv, const float *Nmat,
                    const int32_t *object_id);
 
+/* Cones (Objects.h:188-278): the unit cone (apex at the origin, opening towards +y, closed by the disc y = 1) under
+ * a transformation; same three matrices as a sphere.  Spheres + cones: at most 64.  Optional (default: none). */
+int rt_set_cones(rt_context *ctx, int32_t n, const float *M, const float *Minv, const float *Nmat,
+                 const int32_t *object_id);
+
 /* Planes (Objects.h:109-183): point[n*3], normal[n*3]. */
 int rt_set_planes(rt_context *ctx, int32_t n, const float *point, const float *normal, const int32_t *object_id);
 

@@ -30,6 +30,8 @@ class SceneDesc(C.Structure):
         ("n_lights", C.c_int32), ("light_pos", C.c_void_p), ("light_color", C.c_void_p),
         ("ambient", C.c_float * 3),
         ("bmp_w", C.c_int32 * 4), ("bmp_h", C.c_int32 * 4), ("bmp_c", C.c_int32 * 4), ("bmp", C.c_void_p * 4),
+        ("n_cones", C.c_int32), ("cone_M", C.c_void_p), ("cone_Minv", C.c_void_p), ("cone_N", C.c_void_p),
+        ("cone_object", C.c_void_p),
     ]
 
 
@@ -76,7 +78,7 @@ class Oracle:
         self._keep = [np.ascontiguousarray(a) for a in (
             s.materials, s.object_material, s.v0, s.v1, s.v2, s.nA, s.nB, s.nC, s.tA, s.tB, s.tC, s.tri_flags,
             s.tri_object, s.sph_M, s.sph_Minv, s.sph_N, s.sph_object, s.pl_point, s.pl_normal, s.pl_object,
-            s.light_pos, s.light_color)]
+            s.light_pos, s.light_color, s.cone_M, s.cone_Minv, s.cone_N, s.cone_object)]
         k = self._keep
         d.n_materials, d.materials = len(s.materials), _p(k[0])
         d.n_objects, d.object_material = s.n_objects, _p(k[1])
@@ -88,6 +90,8 @@ class Oracle:
         d.pl_point, d.pl_normal, d.pl_object = [_p(a) for a in k[17:20]]
         d.n_lights = len(s.light_pos)
         d.light_pos, d.light_color = _p(k[20]), _p(k[21])
+        d.n_cones = len(s.cone_object)
+        d.cone_M, d.cone_Minv, d.cone_N, d.cone_object = [_p(a) for a in k[22:26]]
         for i in range(3):
             d.ambient[i] = float(s.ambient[i])
         self._bmps = []

@@ -107,6 +107,25 @@ def gen_meshes(tmp):
     np.savez_compressed(os.path.join(GOLD, "meshes.npz"), meta=json.dumps(meta), **keep)
 
 
+def gen_scene_dump(tmp, name="cones"):
+    """analytic primitives of a harness scene as the reference objects hold them (matrices of spheres / cones)"""
+    o = os.path.join(tmp, "s.out")
+    run(O2, "scene", name, o)
+    raw = np.fromfile(o, np.float32)
+    units, planes, k = [], [], 0
+    while k < len(raw):
+        tag = int(raw[k])
+        if tag in (1, 4):
+            units.append(np.concatenate([[tag], raw[k + 1:k + 49]]))
+            k += 49
+        elif tag == 2:
+            planes.append(raw[k + 1:k + 7])
+            k += 7
+        else:
+            k += 2
+    np.savez_compressed(os.path.join(GOLD, f"scene_{name}.npz"), units=np.array(units, np.float32), planes=np.array(planes, np.float32))
+
+
 def scene_rays(scene, n, seed):
     """primary-like rays from the scene camera + rays between random points of the scene box"""
     rng = np.random.default_rng(seed)
@@ -125,8 +144,10 @@ def scene_rays(scene, n, seed):
     return np.concatenate([prim, np.concatenate([a, dd], 1)]).astype(np.float32)
 
 
-def gen_rays(tmp):
-    for name, n in (("sample", 4096), ("competition", 4096), ("bunny", 1024)):
+def gen_rays(tmp, only=None):
+    for name, n in (("sample", 4096), ("competition", 4096), ("bunny", 1024), ("cones", 3072)):
+        if only and only != name:
+            continue
         scene = FlatScene.builtin(name, lazy=True)
         rays = scene_rays(scene, n, seed=10 + len(name))
         d = rays[:, 3:].astype(np.float32)
@@ -152,6 +173,8 @@ RENDERS = [  # name, scene, w, h, spp, depth, seed
     ("competition_96x72_spp16", "competition", 96, 72, 16, 3, 7),
     ("sample_160x105_depth0", "sample", 160, 105, 4, 0, 0),
     ("competition_100x70_depth1", "competition", 100, 70, 4, 1, 0),  # ragged tiles (100 = 6*16+4, 70 = 4*16+6)
+    ("cones_320x240", "cones", 320, 240, 4, 3, 0),                  # Cone primitive
+    ("cones_150x110_spp16", "cones", 150, 110, 16, 3, 3),
 ]
 
 
@@ -194,7 +217,11 @@ def main():
             gen_meshes(tmp)
         if a.only in (None, "rays"):
             gen_rays(tmp)
-        if a.only is None or a.only.startswith(("render", "sample", "competition", "bunny")):
+        if a.only in (None, "scene_cones"):
+            gen_scene_dump(tmp, "cones")
+        if a.only == "rays_cones":
+            gen_rays(tmp, "cones")
+        if a.only is None or a.only.startswith(("render", "sample", "competition", "bunny", "cones_")):
             t = gen_renders(tmp, None if a.only in (None, "render") else a.only)
             if a.only in (None, "render"):
                 with open(os.path.join(GOLD, "ref_timing.json"), "w") as f:

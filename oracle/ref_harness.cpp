@@ -63,7 +63,70 @@ static Camera competition_camera() {
     return {glm::vec3(-0.45, -0.21, 1.52), r, -1.0f};
 }
 
+// a scene for the Cone primitive (Objects.h:188-278), which neither shipped scene instantiates.
+// Defined here with the reference's own classes; raytracer_amd/host/Scenes.cpp (coneScene) restates it through the
+// kept surface.  Cones: apex at the object-space origin, opening towards +y, cap at y = 1.
+static void cones_scene() {
+    Material matte, mirror, glass, perla, brushed, ground, wall;
+    matte.ambient = glm::vec3(0.02f, 0.02f, 0.05f);
+    matte.diffuse = glm::vec3(0.3f, 0.4f, 0.9f);
+    matte.specular = glm::vec3(0.3f);
+    matte.shininess = 10.0f;
+    mirror.reflection = 0.8f;
+    mirror.diffuse = glm::vec3(0.1f);
+    mirror.specular = glm::vec3(0.5f);
+    mirror.shininess = 50.0f;
+    glass.diffuse = glm::vec3(0.0f);
+    glass.refraction = 1.0f;
+    glass.reflection = 1.0f;
+    glass.sigma = 1.5f;
+    perla.ambient = glm::vec3(0.05f);
+    perla.texture = &opal;
+    perla.refraction = 0.5f;
+    perla.reflection = 0.1f;
+    perla.sigma = 2.0f;
+    brushed.ambient = glm::vec3(0.01f, 0.03f, 0.03f);
+    brushed.diffuse = glm::vec3(0.8f, 0.4f, 0.1f);
+    brushed.specular = glm::vec3(0.6f);
+    brushed.isAnisotropic = true;
+    ground.ambient = glm::vec3(0.03f);
+    ground.texture = &perlinTerrain;
+    wall.diffuse = glm::vec3(0.6f, 0.6f, 0.5f);
+    wall.specular = glm::vec3(0.2f);
+    wall.shininess = 20.0f;
+    wall.hasNormalMap = true;
+    wall.normalMap = &perlinNormal;
+
+    objects.push_back(new MeshLoader("./meshes/bunny.obj", glm::vec3(-1.0f, -3.0f, 6.5f), true, matte));
+    objects.push_back(new Plane(glm::vec3(0.0f, -3.0f, 0.0f), glm::vec3(0.0f, 1.0f, 0.0f), true, ground));
+    objects.push_back(new Plane(glm::vec3(0.0f, 0.0f, 18.0f), glm::vec3(0.0f, 0.0f, -1.0f), true, wall));
+    objects.push_back(new Plane(glm::vec3(-9.0f, 0.0f, 0.0f), glm::vec3(1.0f, 0.0f, 0.0f), true, matte));
+    struct { const Material *m; glm::vec3 at; float angle; glm::vec3 axis; glm::vec3 scale; } cones[6] = {
+        {&matte, glm::vec3(-3.5f, -3.0f, 9.0f), 0.0f, glm::vec3(1, 0, 0), glm::vec3(1.5f, 3.0f, 1.5f)},              // apex down
+        {&mirror, glm::vec3(2.5f, 0.5f, 11.0f), 3.14159265f, glm::vec3(1, 0, 0), glm::vec3(1.4f, 3.5f, 1.4f)},      // upright
+        {&glass, glm::vec3(0.3f, -1.2f, 6.0f), 0.6f, glm::vec3(0, 0, 1), glm::vec3(0.8f, 1.6f, 0.8f)},              // tilted
+        {&perla, glm::vec3(4.5f, -3.0f, 7.5f), 0.0f, glm::vec3(1, 0, 0), glm::vec3(1.0f, 2.0f, 1.0f)},
+        {&brushed, glm::vec3(-4.5f, 1.5f, 13.0f), 2.5f, glm::vec3(1, 0, 1), glm::vec3(1.5f, 2.0f, 1.5f)},
+        {&mirror, glm::vec3(0.0f, 3.0f, 14.0f), 1.5707963f, glm::vec3(0, 0, 1), glm::vec3(2.0f, 1.0f, 0.5f)},       // squashed
+    };
+    for (auto &c : cones) {
+        Cone *cone = new Cone(*c.m);
+        cone->setTransformation(glm::translate(c.at) * glm::rotate(glm::mat4(1.0f), c.angle, c.axis) * glm::scale(c.scale));
+        objects.push_back(cone);
+    }
+    Sphere *s = new Sphere(mirror);
+    s->setTransformation(glm::translate(glm::vec3(-6.0f, -1.5f, 12.0f)) * glm::scale(glm::vec3(1.5f)));
+    objects.push_back(s);
+    lights.push_back(new Light(glm::vec3(0.0f, 10.0f, 4.0f), glm::vec3(60.0f)));
+    lights.push_back(new Light(glm::vec3(-6.0f, 3.0f, 2.0f), glm::vec3(25.0f)));
+    lights.push_back(new Light(glm::vec3(5.0f, 1.0f, 0.0f), glm::vec3(15.0f)));
+}
+
 static Camera load_scene(const std::string &name) {
+    if (name == "cones") {
+        cones_scene();
+        return sample_camera();
+    }
     if (name == "sample") {
         sampleScene();
         return sample_camera();
@@ -307,7 +370,7 @@ static int cmd_rays(int argc, char **argv) {
 // ---------------------------------------------------------------------------------------------
 static int cmd_scene(int argc, char **argv) {
     // scene <scene> <out.f32>: dump analytic primitives + lights so the host surface can be checked
-    // spheres: 48 floats (M, Minv, Nmat column-major); planes: 6 floats (point, normal)
+    // spheres (tag 1) and cones (tag 4): 48 floats (M, Minv, Nmat column-major); planes: 6 floats (point, normal)
     std::string scene = argv[2];
     load_scene(scene);
     std::vector<float> o;
@@ -315,6 +378,12 @@ static int cmd_scene(int argc, char **argv) {
         if (Sphere *s = dynamic_cast<Sphere *>(ob)) {
             o.push_back(1.f);
             const glm::mat4 *ms[3] = {&s->transformationMatrix, &s->inverseTransformationMatrix, &s->normalMatrix};
+            for (auto m : ms)
+                for (int c = 0; c < 4; c++)
+                    for (int r = 0; r < 4; r++) o.push_back((*m)[c][r]);
+        } else if (Cone *cn = dynamic_cast<Cone *>(ob)) {
+            o.push_back(4.f);
+            const glm::mat4 *ms[3] = {&cn->transformationMatrix, &cn->inverseTransformationMatrix, &cn->normalMatrix};
             for (auto m : ms)
                 for (int c = 0; c < 4; c++)
                     for (int r = 0; r < 4; r++) o.push_back((*m)[c][r]);

@@ -219,12 +219,13 @@ struct Scene {
     std::vector<Tri> tris;
     std::vector<Mesh> meshes;
     std::vector<Sphere> spheres;
+    std::vector<Sphere> cones;  // same record: three matrices + object
     std::vector<Plane> planes;
     std::vector<Light> lights;
     V3 ambient{0, 0, 0};
     int bw[4] = {0, 0, 0, 0}, bh[4] = {0, 0, 0, 0}, bc[4] = {0, 0, 0, 0};
     std::vector<uint8_t> bmp[4];
-    // scene order: kind 0 mesh, 1 sphere, 2 plane; idx into the respective vector
+    // scene order: kind 0 mesh, 1 sphere, 2 plane, 3 cone; idx into the respective vector
     struct Ref { int kind, idx; };
     std::vector<Ref> order;
 };
@@ -375,6 +376,54 @@ Hit sphereIntersect(const Scene &s, const Sphere &sp, V3 o, V3 d) {
     return hit;
 }
 
+// Cone::intersect, Objects.h:212-276 (its base is Plane(point (0,1,0), normal (0,1,0)), Objects.h:138-158)
+Hit coneIntersect(const Scene &s, const Sphere &cn, V3 o, V3 d) {
+    Hit hit;
+    const float height = 1.0;
+    V3 no = mulPoint(cn.Minv, o, 1.0f);
+    V3 nd = normalize(mulPoint(cn.Minv, d, 0.0f));
+    float a = nd.x * nd.x + nd.z * nd.z - nd.y * nd.y;
+    float b = 2 * (no.x * nd.x + no.z * nd.z - no.y * nd.y);
+    float c = no.x * no.x + no.z * no.z - no.y * no.y;
+    float delta = b * b - 4 * a * c;
+    if (delta < 0) return hit;
+    float t1 = (-b - std::sqrt(delta)) / (2 * a);
+    float t2 = (-b + std::sqrt(delta)) / (2 * a);
+    float t = t1;
+    V3 ni = no + t * nd;
+    if (t < 0 || ni.y > height || ni.y < 0) {
+        t = t2;
+        ni = no + t * nd;
+        if (t < 0 || ni.y > height || ni.y < 0) return hit;
+    }
+    V3 nn = normalize(v3(ni.x, -ni.y, ni.z));
+    {  // base->intersect(Ray(newOrigin, newDirection)), Objects.h:246-253
+        const V3 bn = v3(0.0f, 1.0f, 0.0f);
+        float ddotN = dot(nd, bn);
+        if (ddotN != 0) {
+            float podotN = dot(bn - no, bn);
+            float tb = podotN / ddotN;
+            if (!(tb < 0)) {
+                V3 bi = no + tb * nd;
+                if (tb < t && length(bi - bn) <= 1.0) {
+                    ni = bi;
+                    nn = bn;
+                }
+            }
+        }
+    }
+    hit.hit = true;
+    hit.object = cn.object;
+    hit.P = mulPoint(cn.M, ni, 1.0f);
+    hit.distance = length(hit.P - o);  // glm::distance
+    V3 ng = normalize(mulPoint(cn.N, nn, 0.0f));
+    hit.normal = ng;
+    hit.ns = ng;  // "cone has no normal map available"
+    hit.uv.x = (float)((std::asin((double)nn.y) + M_PI / 2) / M_PI);
+    hit.uv.y = (float)((std::atan2((double)nn.z, (double)nn.x) + M_PI) / (2 * M_PI));
+    return hit;
+}
+
 // Plane::intersect, Objects.h:138-182
 Hit planeIntersect(const Scene &s, const Plane &pl, V3 o, V3 d) {
     const rt_material &mat = s.materials[s.object_material[pl.object]];
@@ -408,6 +457,7 @@ Hit planeIntersect(const Scene &s, const Plane &pl, V3 o, V3 d) {
 Hit objectIntersect(const Scene &s, const Scene::Ref &r, V3 o, V3 d) {
     if (r.kind == 0) return meshIntersect(s, s.meshes[r.idx], o, d);
     if (r.kind == 1) return sphereIntersect(s, s.spheres[r.idx], o, d);
+    if (r.kind == 3) return coneIntersect(s, s.cones[r.idx], o, d);
     return planeIntersect(s, s.planes[r.idx], o, d);
 }
 
@@ -696,6 +746,8 @@ ro_scene *ro_create(const ro_scene_desc *d) {
     }
     for (int k = 0; k < d->n_spheres; k++)
         s.spheres.push_back(Sphere{loadM4(d->sph_M + 16 * k), loadM4(d->sph_Minv + 16 * k), loadM4(d->sph_N + 16 * k), d->sph_object[k]});
+    for (int k = 0; k < d->n_cones; k++)
+        s.cones.push_back(Sphere{loadM4(d->cone_M + 16 * k), loadM4(d->cone_Minv + 16 * k), loadM4(d->cone_N + 16 * k), d->cone_object[k]});
     for (int k = 0; k < d->n_planes; k++) s.planes.push_back(Plane{g3(d->pl_point, k), g3(d->pl_normal, k), d->pl_object[k]});
     for (int k = 0; k < d->n_lights; k++) s.lights.push_back(Light{g3(d->light_pos, k), g3(d->light_color, k)});
     s.ambient = v3(d->ambient[0], d->ambient[1], d->ambient[2]);
@@ -725,6 +777,7 @@ ro_scene *ro_create(const ro_scene_desc *d) {
     for (size_t i = 0; i < s.meshes.size(); i++) s.order[s.meshes[i].object] = Scene::Ref{0, (int)i};
     for (size_t i = 0; i < s.spheres.size(); i++) s.order[s.spheres[i].object] = Scene::Ref{1, (int)i};
     for (size_t i = 0; i < s.planes.size(); i++) s.order[s.planes[i].object] = Scene::Ref{2, (int)i};
+    for (size_t i = 0; i < s.cones.size(); i++) s.order[s.cones[i].object] = Scene::Ref{3, (int)i};
     std::vector<Scene::Ref> live;
     for (auto &r : s.order)
         if (r.kind >= 0) live.push_back(r);

@@ -39,6 +39,10 @@ typedef struct ro_scene_desc {
     /* BMP slots 0..3 (color, normal, roughness, occlusion), top-down BGR; width 0 = absent */
     int32_t bmp_w[4], bmp_h[4], bmp_c[4];
     const uint8_t *bmp[4];
+    /* cones (Objects.h:188-278): same three matrices as spheres */
+    int32_t n_cones;
+    const float *cone_M, *cone_Minv, *cone_N;
+    const int32_t *cone_object;
 } ro_scene_desc;
 
 ro_scene *ro_create(const ro_scene_desc *d);

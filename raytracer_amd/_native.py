@@ -98,6 +98,7 @@ def hip_lib():
     lib.rt_set_triangles.argtypes = [VP, I64] + [VP] * 11
     lib.rt_set_spheres.argtypes = [VP, I32, VP, VP, VP, VP]
     lib.rt_set_planes.argtypes = [VP, I32, VP, VP, VP]
+    lib.rt_set_cones.argtypes = [VP, I32, VP, VP, VP, VP]
     lib.rt_set_lights.argtypes = [VP, I32, VP, VP, VP]
     lib.rt_set_bmp.argtypes = [VP, I32, I32, I32, I32, VP]
     lib.rt_commit.argtypes = [VP]
@@ -135,6 +136,7 @@ def host_lib(lazy=False):
     lib.rth_scene_get_triangles.argtypes = [VP] * 12
     lib.rth_scene_get_analytic.argtypes = [VP] * 8
     lib.rth_scene_get_shading.argtypes = [VP] * 6
+    lib.rth_scene_get_cones.argtypes = [VP] * 5
     lib.rth_read_bmp.argtypes = [C.c_char_p, VP, VP, VP, VP]
     lib.rth_mesh_create.restype = VP
     lib.rth_mesh_create.argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_float, VP]

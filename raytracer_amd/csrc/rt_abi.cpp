@@ -68,7 +68,7 @@ struct rt_context {
     std::vector<float> v0, v1, v2, nA, nB, nC, tA, tB, tC;
     std::vector<uint32_t> tri_flags;
     std::vector<int32_t> tri_object;
-    std::vector<RtSphere> spheres;
+    std::vector<RtSphere> spheres, cones;  // uploaded as one array (RtSphere::kind)
     std::vector<RtPlane> planes;
     std::vector<RtLight> lights;
     float ambient[3] = {0, 0, 0};
@@ -431,7 +431,39 @@ int rt_set_spheres(rt_context *ctx, int32_t n, const float *M, const float *Minv
             s.box_mn[a] = (float)(c - r - pad);
             s.box_mx[a] = (float)(c + r + pad);
         }
+        s.kind = RT_KIND_SPHERE;
         std::memset(s._pad, 0, sizeof s._pad);
+    }
+    ctx->committed = false;
+    return 0;
+}
+
+int rt_set_cones(rt_context *ctx, int32_t n, const float *M, const float *Minv, const float *Nmat, const int32_t *object_id) {
+    if (!ctx || n < 0 || n > RT_MAX_SPHERES || (n && (!M || !Minv || !Nmat || !object_id))) return fail("rt_set_cones: bad arguments (at most 64 spheres + cones)");
+    ctx->cones.resize(n);
+    for (int k = 0; k < n; k++) {
+        RtSphere &s = ctx->cones[k];
+        std::memset(&s, 0, sizeof s);
+        std::memcpy(s.M, M + 16 * k, 64);
+        std::memcpy(s.Minv, Minv + 16 * k, 64);
+        std::memcpy(s.N, Nmat + 16 * k, 64);
+        s.object = object_id[k];
+        s.kind = RT_KIND_CONE;
+        // world bounds of the object-space box [-1,1] x [0,1] x [-1,1] that holds the unit cone and its cap
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < 8; c++) {
+            const double x = (c & 1) ? 1.0 : -1.0, y = (c & 2) ? 1.0 : 0.0, z = (c & 4) ? 1.0 : -1.0;
+            for (int ax = 0; ax < 3; ax++) {
+                const double v = s.M[ax] * x + s.M[4 + ax] * y + s.M[8 + ax] * z + s.M[12 + ax];
+                mn[ax] = std::fmin(mn[ax], v);
+                mx[ax] = std::fmax(mx[ax], v);
+            }
+        }
+        for (int ax = 0; ax < 3; ax++) {
+            const double pad = 1e-3 * (mx[ax] - mn[ax]) + 1e-5 * std::fmax(std::fabs(mn[ax]), std::fabs(mx[ax])) + 1e-30;
+            s.box_mn[ax] = (float)(mn[ax] - pad);
+            s.box_mx[ax] = (float)(mx[ax] + pad);
+        }
     }
     ctx->committed = false;
     return 0;
@@ -484,10 +516,14 @@ int rt_commit(rt_context *ctx) {
     auto objOk = [&](int o) { return o >= 0 && o < n_obj; };
     for (int64_t k = 0; k < nt; k++)
         if (!objOk(ctx->tri_object[k])) return fail("rt_commit: triangle object_id out of range");
-    for (RtSphere &s : ctx->spheres) {
-        if (!objOk(s.object)) return fail("rt_commit: sphere object_id out of range");
-        s.material = ctx->object_material[s.object];
-    }
+    if (ctx->spheres.size() + ctx->cones.size() > RT_MAX_SPHERES) return fail("rt_commit: more than 64 spheres + cones");
+    for (std::vector<RtSphere> *v : {&ctx->spheres, &ctx->cones})
+        for (RtSphere &s : *v) {
+            if (!objOk(s.object)) return fail("rt_commit: sphere / cone object_id out of range");
+            s.material = ctx->object_material[s.object];
+        }
+    std::vector<RtSphere> units = ctx->spheres;  // spheres, then cones: one device array
+    units.insert(units.end(), ctx->cones.begin(), ctx->cones.end());
     for (RtPlane &p : ctx->planes) {
         if (!objOk(p.object)) return fail("rt_commit: plane object_id out of range");
         p.material = ctx->object_material[p.object];
@@ -541,7 +577,7 @@ int rt_commit(rt_context *ctx) {
         s._pad = 0;
     }
     if (ctx->d_records.upload(records) || ctx->d_shade.upload(shade) || ctx->d_nodes_p.upload(ctx->bvh.nodes_p)) return 1;
-    if (ctx->d_spheres.upload(ctx->spheres) || ctx->d_planes.upload(ctx->planes)) return 1;
+    if (ctx->d_spheres.upload(units) || ctx->d_planes.upload(ctx->planes)) return 1;
     if (ctx->d_materials.upload(ctx->materials) || ctx->d_objmat.upload(ctx->object_material) || ctx->d_lights.upload(ctx->lights)) return 1;
     RtSceneDev &d = ctx->dev;
     std::memset(&d, 0, sizeof d);
@@ -565,7 +601,7 @@ int rt_commit(rt_context *ctx) {
     std::memcpy(d.ambient, ctx->ambient, 12);
     d.n_nodes = (int)ctx->bvh.nodes.size();
     d.n_tris = (int)nt;
-    d.n_spheres = (int)ctx->spheres.size();
+    d.n_spheres = (int)units.size();
     d.n_planes = (int)ctx->planes.size();
     d.n_lights = (int)ctx->lights.size();
     d.n_objects = n_obj;
@@ -579,7 +615,7 @@ int rt_commit(rt_context *ctx) {
         int a = 1, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2) { ctx->cfg.packet_levels_closest = a; ctx->cfg.packet_levels_any = b; }
     }
-    ctx->cfg.analytic_bytes = (int)(ctx->spheres.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
+    ctx->cfg.analytic_bytes = (int)(units.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
     const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
     const size_t spill_entries = (size_t)std::max(0, ctx->bvh.max_stack - entries);

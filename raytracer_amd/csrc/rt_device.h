@@ -208,6 +208,47 @@ RT_DEV bool rtSphereHit(const RtSphere &sp, const RtRay &r, float &dist, V3 &ni,
     return true;
 }
 
+// Cone::intersect up to the object-space hit, Objects.h:212-254: unit cone x^2 + z^2 = y^2 for 0 <= y <= 1 (apex at the
+// origin) closed by the disc y = 1.  ni = object-space intersection, nn = object-space normal, P = world intersection.
+RT_DEV bool rtConeHit(const RtSphere &sp, const RtRay &r, float &dist, V3 &ni, V3 &nn, V3 &P) {
+    const float height = 1.0f;
+    const V3 no = mulPoint(sp.Minv, r.o, 1.0f);
+    const V3 nd = normalize(mulPoint(sp.Minv, r.d, 0.0f));
+    const float a = nd.x * nd.x + nd.z * nd.z - nd.y * nd.y;
+    const float b = 2 * (no.x * nd.x + no.z * nd.z - no.y * nd.y);
+    const float c = no.x * no.x + no.z * no.z - no.y * no.y;
+    const float delta = b * b - 4 * a * c;
+    if (delta < 0) return false;
+    const float t1 = (-b - sqrtf(delta)) / (2 * a);
+    const float t2 = (-b + sqrtf(delta)) / (2 * a);
+    float t = t1;
+    ni = no + t * nd;
+    if (t < 0 || ni.y > height || ni.y < 0) {
+        t = t2;
+        ni = no + t * nd;
+        if (t < 0 || ni.y > height || ni.y < 0) return false;
+    }
+    nn = normalize(v3(ni.x, -ni.y, ni.z));
+    // the base, a Plane(point (0,1,0), normal (0,1,0)) intersected in object space (Objects.h:138-158, :246-253):
+    // it replaces the side hit when it is closer and inside the unit disc -- only rays that also hit the side get here
+    const V3 bn = v3(0.0f, 1.0f, 0.0f);
+    const float ddotN = dot(nd, bn);
+    if (ddotN != 0) {
+        const float podotN = dot(bn - no, bn);
+        const float tb = podotN / ddotN;
+        if (!(tb < 0)) {
+            const V3 bi = no + tb * nd;
+            if (tb < t && length(bi - bn) <= 1.0f) {
+                ni = bi;
+                nn = bn;
+            }
+        }
+    }
+    P = mulPoint(sp.M, ni, 1.0f);
+    dist = length(P - r.o);
+    return true;
+}
+
 // Plane::intersect, Objects.h:138-158
 RT_DEV bool rtPlaneHit(const RtPlane &pl, const RtRay &r, float &t) {
     V3 n = ld3(pl.normal);
@@ -217,6 +258,15 @@ RT_DEV bool rtPlaneHit(const RtPlane &pl, const RtRay &r, float &t) {
     t = podotN / ddotN;
     if (t < 0) return false;
     return true;
+}
+
+// either transformed unit primitive, by kind
+RT_DEV bool rtUnitPrimHit(const RtSphere &sp, const RtRay &r, float &dist, V3 &ni, V3 &P) {
+    if (sp.kind == RT_KIND_CONE) {
+        V3 nn;
+        return rtConeHit(sp, r, dist, ni, nn, P);
+    }
+    return rtSphereHit(sp, r, dist, ni, P);
 }
 
 struct RtTri { V3 A, B, C, n; };
@@ -275,9 +325,13 @@ RT_DEV void rtReconstructHit(const RtSceneDev &sc, const RtRay &r, float t, uint
     if (kind == RT_ID_SPHERE) {  // Objects.h:67-95
         const RtSphere &sp = sc.spheres[id & 0xFFFF];
         float dist;
-        V3 ni;
-        rtSphereHit(sp, r, dist, ni, h.P);
-        V3 nn = normalize(ni - v3s(0.0f));
+        V3 ni, nn;
+        if (sp.kind == RT_KIND_CONE) {  // Objects.h:255-275: no normal map on cones, uv from the object-space normal
+            rtConeHit(sp, r, dist, ni, nn, h.P);
+        } else {
+            rtSphereHit(sp, r, dist, ni, h.P);
+            nn = normalize(ni - v3s(0.0f));
+        }
         V3 ng = normalize(mulPoint(sp.N, nn, 0.0f));
         h.normal = ng;
         h.ns = ng;
@@ -288,7 +342,7 @@ RT_DEV void rtReconstructHit(const RtSceneDev &sc, const RtRay &r, float t, uint
         h.material = sp.material;
         h.prim = RT_PRIM_ANALYTIC | (uint32_t)sp.object;
         const rt_material &m = sc.materials[sp.material];
-        if (m.has_normal_map) {
+        if (m.has_normal_map && sp.kind == RT_KIND_SPHERE) {
             h.T = normalize(cross(v3(0.0f, 1.0f, 0.0f), h.P));
             h.B = normalize(cross(h.normal, h.T));
             h.ns = rtApplyNormalMap(sc, m, h.T, h.B, h.normal, h.uv);

@@ -243,7 +243,7 @@ RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &
         if (!sphereBoxHit(sp, w.inv, w.oi)) continue;
         float dist;
         V3 ni, P;
-        if (rtSphereHit(sp, w.r, dist, ni, P) && (dist < w.best_t || (dist == w.best_t && w.best_id != RT_ID_MISS && sp.object < w.best_obj))) {
+        if (rtUnitPrimHit(sp, w.r, dist, ni, P) && (dist < w.best_t || (dist == w.best_t && w.best_id != RT_ID_MISS && sp.object < w.best_obj))) {
             w.best_t = dist;
             w.best_id = RT_ID_SPHERE | (uint32_t)k;
             w.best_obj = sp.object;
@@ -270,7 +270,7 @@ RT_DEV bool analyticOccluded(const RtSceneDev &sc, const RtAnalytic &an, const R
         if (!sphereBoxHit(sp, w.inv, w.oi)) continue;
         float d;
         V3 ni, P;
-        if (rtSphereHit(sp, w.r, d, ni, P) && d <= dist) return true;
+        if (rtUnitPrimHit(sp, w.r, d, ni, P) && d <= dist) return true;
     }
     return false;
 }

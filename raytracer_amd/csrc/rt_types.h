@@ -75,14 +75,17 @@ struct RtTriShade {
     uint32_t _pad;
 };
 
-struct RtSphere {       // Objects.h:12-104; 240 bytes
+struct RtSphere {       // a transformed unit primitive: Sphere (Objects.h:12-104) or Cone (Objects.h:188-278); 240 bytes
     float M[16], Minv[16], N[16];
     int32_t object;
     int32_t material;
-    float box_mn[3], box_mx[3];  // padded world-space bounds of the transformed unit sphere (rt_commit): a ray that
-                                 // misses them cannot hit the sphere, so the exact test is skipped
-    int32_t _pad[4];
+    float box_mn[3], box_mx[3];  // padded world-space bounds of the transformed primitive (rt_commit): a ray that
+                                 // misses them cannot hit it, so the exact test is skipped
+    int32_t kind;                // RT_KIND_SPHERE / RT_KIND_CONE
+    int32_t _pad[3];
 };
+#define RT_KIND_SPHERE 0
+#define RT_KIND_CONE 1
 
 struct RtPlane {        // Objects.h:109-183
     float point[3];

@@ -1,6 +1,5 @@
-// Objects.h -- analytic primitives of the scene-definition surface: Sphere and Plane with the constructors
-// of the reference (Objects.h:25,31,127).  Cone (Objects.h:188) is not instantiated by either shipped scene
-// and is out of scope this round.
+// Objects.h -- analytic primitives of the scene-definition surface: Sphere, Plane and Cone with the constructors
+// of the reference (Objects.h:25,31,127,198).
 #pragma once
 #include "Object.h"
 
@@ -22,5 +21,13 @@ public:
     }
     glm::vec3 getNormal() const { return normal; }
     glm::vec3 getPoint() const { return point; }
+    void flatten(FlatScene &out, int object_id) const override;
+};
+
+// Unit cone (apex at the origin, opening towards +y, closed by the disc y = 1) under the object's transformation
+// (reference Objects.h:188-278; the base Plane the reference allocates is part of the GPU-side intersection).
+class Cone : public Object {
+public:
+    explicit Cone(Material m) { material = m; }
     void flatten(FlatScene &out, int object_id) const override;
 };

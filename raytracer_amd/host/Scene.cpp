@@ -102,6 +102,12 @@ void Sphere::flatten(FlatScene &out, int object_id) const {
     pushMat(out.sph_N, normalMatrix);
     out.sph_object.push_back(object_id);
 }
+void Cone::flatten(FlatScene &out, int object_id) const {
+    pushMat(out.cone_M, transformationMatrix);
+    pushMat(out.cone_Minv, inverseTransformationMatrix);
+    pushMat(out.cone_N, normalMatrix);
+    out.cone_object.push_back(object_id);
+}
 void Plane::flatten(FlatScene &out, int object_id) const {
     push3(out.pl_point, point);
     push3(out.pl_normal, normal);
@@ -138,6 +144,7 @@ void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture
                              s.nC.data(), s.tA.data(), s.tB.data(), s.tC.data(), s.tri_flags.data(), s.tri_object.data()),
             "rt_set_triangles");
     rtCheck(rt_set_spheres(ctx, (int32_t)s.sph_object.size(), s.sph_M.data(), s.sph_Minv.data(), s.sph_N.data(), s.sph_object.data()), "rt_set_spheres");
+    rtCheck(rt_set_cones(ctx, (int32_t)s.cone_object.size(), s.cone_M.data(), s.cone_Minv.data(), s.cone_N.data(), s.cone_object.data()), "rt_set_cones");
     rtCheck(rt_set_planes(ctx, (int32_t)s.pl_object.size(), s.pl_point.data(), s.pl_normal.data(), s.pl_object.data()), "rt_set_planes");
     rtCheck(rt_set_lights(ctx, (int32_t)(s.light_pos.size() / 3), s.light_pos.data(), s.light_color.data(), s.ambient), "rt_set_lights");
     if (s.uses_bmp) {  // Textures.h:168-171

@@ -53,6 +53,8 @@ struct FlatScene {
     std::vector<int32_t> tri_object;
     std::vector<float> sph_M, sph_Minv, sph_N;
     std::vector<int32_t> sph_object;
+    std::vector<float> cone_M, cone_Minv, cone_N;
+    std::vector<int32_t> cone_object;
     std::vector<float> pl_point, pl_normal;
     std::vector<int32_t> pl_object;
     std::vector<float> light_pos, light_color;
@@ -91,5 +93,6 @@ std::vector<glm::vec3> trace_rays(const std::vector<Ray> &rays, int bounces, std
 Camera sampleScene(const std::string &meshDir = "./meshes");         // main.cpp:258-407
 Camera bunnyScene(const std::string &meshDir = "./meshes");          // sampleScene minus the spheres
 Camera competitionScene(const std::string &meshDir = "./meshes");    // main.cpp:409-536 minus the missing pietre.obj
+Camera coneScene(const std::string &meshDir = "./meshes");             // Cone test scene (oracle/ref_harness.cpp: cones_scene)
 Camera stressScene(const std::string &meshDir, int replicas);        // competition meshes on a lattice
 void clearScene();

@@ -219,6 +219,64 @@ Camera competitionScene(const std::string &meshDir) {
     return competitionCamera();
 }
 
+// a scene for the Cone primitive, which neither shipped scene instantiates.  The same scene is
+// defined with the reference's own classes in oracle/ref_harness.cpp (cones_scene) -- that is where its golden
+// fixtures come from.
+Camera coneScene(const std::string &meshDir) {
+    Material matte, mirror, glass, perla, brushed, ground, wall;
+    matte.ambient = glm::vec3(0.02f, 0.02f, 0.05f);
+    matte.diffuse = glm::vec3(0.3f, 0.4f, 0.9f);
+    matte.specular = glm::vec3(0.3f);
+    matte.shininess = 10.0f;
+    mirror.reflection = 0.8f;
+    mirror.diffuse = glm::vec3(0.1f);
+    mirror.specular = glm::vec3(0.5f);
+    mirror.shininess = 50.0f;
+    glass.diffuse = glm::vec3(0.0f);
+    glass.refraction = 1.0f;
+    glass.reflection = 1.0f;
+    glass.sigma = 1.5f;
+    perla.ambient = glm::vec3(0.05f);
+    perla.texture = &opal;
+    perla.refraction = 0.5f;
+    perla.reflection = 0.1f;
+    perla.sigma = 2.0f;
+    brushed.ambient = glm::vec3(0.01f, 0.03f, 0.03f);
+    brushed.diffuse = glm::vec3(0.8f, 0.4f, 0.1f);
+    brushed.specular = glm::vec3(0.6f);
+    brushed.isAnisotropic = true;
+    ground.ambient = glm::vec3(0.03f);
+    ground.texture = &perlinTerrain;
+    wall.diffuse = glm::vec3(0.6f, 0.6f, 0.5f);
+    wall.specular = glm::vec3(0.2f);
+    wall.shininess = 20.0f;
+    wall.hasNormalMap = true;
+    wall.normalMap = &perlinNormal;
+
+    addMesh(meshDir, "bunny.obj", glm::vec3(-1.0f, -3.0f, 6.5f), matte);
+    objects.push_back(new Plane(glm::vec3(0.0f, -3.0f, 0.0f), glm::vec3(0.0f, 1.0f, 0.0f), true, ground));
+    objects.push_back(new Plane(glm::vec3(0.0f, 0.0f, 18.0f), glm::vec3(0.0f, 0.0f, -1.0f), true, wall));
+    objects.push_back(new Plane(glm::vec3(-9.0f, 0.0f, 0.0f), glm::vec3(1.0f, 0.0f, 0.0f), true, matte));
+    struct { const Material *m; glm::vec3 at; float angle; glm::vec3 axis; glm::vec3 scale; } cones[6] = {
+        {&matte, glm::vec3(-3.5f, -3.0f, 9.0f), 0.0f, glm::vec3(1, 0, 0), glm::vec3(1.5f, 3.0f, 1.5f)},          // apex down
+        {&mirror, glm::vec3(2.5f, 0.5f, 11.0f), 3.14159265f, glm::vec3(1, 0, 0), glm::vec3(1.4f, 3.5f, 1.4f)},  // upright
+        {&glass, glm::vec3(0.3f, -1.2f, 6.0f), 0.6f, glm::vec3(0, 0, 1), glm::vec3(0.8f, 1.6f, 0.8f)},          // tilted
+        {&perla, glm::vec3(4.5f, -3.0f, 7.5f), 0.0f, glm::vec3(1, 0, 0), glm::vec3(1.0f, 2.0f, 1.0f)},
+        {&brushed, glm::vec3(-4.5f, 1.5f, 13.0f), 2.5f, glm::vec3(1, 0, 1), glm::vec3(1.5f, 2.0f, 1.5f)},
+        {&mirror, glm::vec3(0.0f, 3.0f, 14.0f), 1.5707963f, glm::vec3(0, 0, 1), glm::vec3(2.0f, 1.0f, 0.5f)},   // squashed
+    };
+    for (auto &c : cones) {
+        Cone *cone = new Cone(*c.m);
+        cone->setTransformation(glm::translate(c.at) * glm::rotate(glm::mat4(1.0f), c.angle, c.axis) * glm::scale(c.scale));
+        objects.push_back(cone);
+    }
+    addSphere(mirror, glm::vec3(-6.0f, -1.5f, 12.0f), 1.5f);
+    addLight(glm::vec3(0.0f, 10.0f, 4.0f), 60.0f);
+    addLight(glm::vec3(-6.0f, 3.0f, 2.0f), 25.0f);
+    addLight(glm::vec3(5.0f, 1.0f, 0.0f), 15.0f);
+    return Camera();
+}
+
 // the 16 competition mesh instances replicated on a translation lattice (synthetic, no
 // reference counterpart).  replica r sits at lattice cell (ix, iz) with spacing 3.5 in x and z.
 Camera stressScene(const std::string &meshDir, int replicas) {

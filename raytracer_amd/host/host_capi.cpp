@@ -32,6 +32,7 @@ void *rth_scene_create(const char *name, const char *asset_dir) {
         if (n == "sample") hs->camera = sampleScene(meshes);
         else if (n == "bunny") hs->camera = bunnyScene(meshes);
         else if (n == "competition") hs->camera = competitionScene(meshes);
+        else if (n == "cones") hs->camera = coneScene(meshes);
         else if (n.rfind("stress:", 0) == 0) hs->camera = stressScene(meshes, std::atoi(n.c_str() + 7));
         else throw std::runtime_error("unknown scene '" + n + "'");
         hs->flat = flattenScene(objects, lights, ambient_light);
@@ -47,7 +48,7 @@ void *rth_scene_create(const char *name, const char *asset_dir) {
 
 void rth_scene_destroy(void *h) { delete (HostScene *)h; }
 
-// counts[8] = triangles, spheres, planes, materials, objects, lights, uses_bmp, 0
+// counts[8] = triangles, spheres, planes, materials, objects, lights, uses_bmp, cones
 int rth_scene_counts(void *h, int64_t *counts) {
     const FlatScene &s = ((HostScene *)h)->flat;
     counts[0] = s.triangleCount();
@@ -57,7 +58,7 @@ int rth_scene_counts(void *h, int64_t *counts) {
     counts[4] = (int64_t)s.object_material.size();
     counts[5] = (int64_t)s.light_pos.size() / 3;
     counts[6] = s.uses_bmp ? 1 : 0;
-    counts[7] = 0;
+    counts[7] = (int64_t)s.cone_object.size();
     return 0;
 }
 
@@ -82,6 +83,12 @@ int rth_scene_get_analytic(void *h, float *sph_M, float *sph_Minv, float *sph_N,
     const FlatScene &s = ((HostScene *)h)->flat;
     copyOut(sph_M, s.sph_M); copyOut(sph_Minv, s.sph_Minv); copyOut(sph_N, s.sph_N); copyOut(sph_object, s.sph_object);
     copyOut(pl_point, s.pl_point); copyOut(pl_normal, s.pl_normal); copyOut(pl_object, s.pl_object);
+    return 0;
+}
+
+int rth_scene_get_cones(void *h, float *M, float *Minv, float *Nmat, int32_t *object_id) {
+    const FlatScene &s = ((HostScene *)h)->flat;
+    copyOut(M, s.cone_M); copyOut(Minv, s.cone_Minv); copyOut(Nmat, s.cone_N); copyOut(object_id, s.cone_object);
     return 0;
 }
 

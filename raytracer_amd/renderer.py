@@ -54,6 +54,7 @@ class Renderer:
         arrs = [c(a, np.float32) for a in (s.v0, s.v1, s.v2, s.nA, s.nB, s.nC, s.tA, s.tB, s.tC)]
         self._check(L.rt_set_triangles(ctx, s.n_triangles, *[_p(a) for a in arrs], _p(c(s.tri_flags)), _p(c(s.tri_object))))
         self._check(L.rt_set_spheres(ctx, len(s.sph_object), _p(c(s.sph_M)), _p(c(s.sph_Minv)), _p(c(s.sph_N)), _p(c(s.sph_object))))
+        self._check(L.rt_set_cones(ctx, len(s.cone_object), _p(c(s.cone_M)), _p(c(s.cone_Minv)), _p(c(s.cone_N)), _p(c(s.cone_object))))
         self._check(L.rt_set_planes(ctx, len(s.pl_object), _p(c(s.pl_point)), _p(c(s.pl_normal)), _p(c(s.pl_object))))
         self._check(L.rt_set_lights(ctx, len(s.light_pos), _p(c(s.light_pos)), _p(c(s.light_color)), _p(c(s.ambient, np.float32))))
         for slot, b in enumerate(s.bmp):

@@ -27,6 +27,8 @@ class FlatScene:
         self.tri_object = np.zeros(0, np.int32)
         self.sph_M = self.sph_Minv = self.sph_N = np.zeros((0, 16), np.float32)
         self.sph_object = np.zeros(0, np.int32)
+        self.cone_M = self.cone_Minv = self.cone_N = np.zeros((0, 16), np.float32)
+        self.cone_object = np.zeros(0, np.int32)
         self.pl_point = self.pl_normal = z3
         self.pl_object = np.zeros(0, np.int32)
         self.light_pos = self.light_color = z3
@@ -83,6 +85,10 @@ class FlatScene:
         s.pl_object = np.zeros(npl, np.int32)
         lib.rth_scene_get_analytic(h, *[_ptr(a) for a in (s.sph_M, s.sph_Minv, s.sph_N, s.sph_object, s.pl_point,
                                                           s.pl_normal, s.pl_object)])
+        nc = int(counts[7])
+        s.cone_M, s.cone_Minv, s.cone_N = (np.zeros((nc, 16), np.float32) for _ in range(3))
+        s.cone_object = np.zeros(nc, np.int32)
+        lib.rth_scene_get_cones(h, *[_ptr(a) for a in (s.cone_M, s.cone_Minv, s.cone_N, s.cone_object)])
         s.materials = np.zeros(nm, dtype=np.dtype((np.void, 96)))
         s.object_material = np.zeros(no, np.int32)
         s.light_pos, s.light_color = f3(nl), f3(nl)
@@ -93,7 +99,7 @@ class FlatScene:
 
     @classmethod
     def builtin(cls, name, asset_dir=None, lazy=False):
-        """name: 'sample' | 'bunny' | 'competition' | 'stress:<replicas>'"""
+        """name: 'sample' | 'bunny' | 'competition' | 'cones' | 'stress:<replicas>'"""
         asset_dir = asset_dir or N.ASSET_DIR
         lib = N.host_lib(lazy=lazy)
         h = lib.rth_scene_create(name.encode(), asset_dir.encode())

@@ -55,7 +55,7 @@ def test_bmp_textures(name):
     assert (np.abs(out - g[name]).max(axis=1) == 0).mean() >= 0.999  # a texel boundary may flip under device fmod
 
 
-@pytest.mark.parametrize("scene", ["sample", "competition", "bunny"])
+@pytest.mark.parametrize("scene", ["sample", "competition", "bunny", "cones"])
 def test_rays_against_reference(scene):
     g = load_golden("rays_" + scene)
     r = renderer_for(scene)
@@ -80,7 +80,8 @@ def test_rays_against_reference(scene):
 
 
 @pytest.mark.parametrize("name", ["sample_320x210", "competition_256x192", "bunny_160x120", "sample_160x105_spp16",
-                                  "competition_96x72_spp16", "sample_160x105_depth0", "competition_100x70_depth1"])
+                                  "competition_96x72_spp16", "sample_160x105_depth0", "competition_100x70_depth1",
+                                  "cones_320x240", "cones_150x110_spp16"])
 def test_render_against_reference(name):
     g = load_golden("render_" + name)
     p = render_params(g)

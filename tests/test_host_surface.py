@@ -81,6 +81,20 @@ def test_sphere_matrices_are_glm_exact(cpu_scene):
     assert np.array_equal(s.sph_N[1].reshape(4, 4), s.sph_Minv[1].reshape(4, 4).T)
 
 
+def test_cone_scene_matrices_match_the_reference(golden, cpu_scene):
+    """Cone (Objects.h:188) through the kept surface: translate * rotate * scale, its inverse and normal matrix must be
+    the bits the reference's own objects hold (tests/golden/scene_cones.npz, dumped by oracle/ref_harness `scene`)"""
+    g = golden("scene_cones")
+    s = cpu_scene("cones")
+    units = g["units"]
+    cones, spheres = units[units[:, 0] == 4][:, 1:], units[units[:, 0] == 1][:, 1:]
+    assert len(s.cone_object) == len(cones) == 6 and len(s.sph_object) == len(spheres) == 1
+    mine = np.concatenate([s.cone_M, s.cone_Minv, s.cone_N], 1)
+    assert np.array_equal(mine.view(np.uint32), np.ascontiguousarray(cones).view(np.uint32))
+    assert np.array_equal(np.concatenate([s.pl_point, s.pl_normal], 1), g["planes"])
+    assert s.n_objects == 11 and s.n_triangles == 1392 and list(s.cone_object) == [4, 5, 6, 7, 8, 9]
+
+
 def test_bmp_decode_orientation():
     img = FlatScene.read_bmp(os.path.join(N.ASSET_DIR, "textures", "basecolor.bmp"))
     assert img.shape == (1024, 1024, 3)

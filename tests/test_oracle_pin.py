@@ -38,7 +38,7 @@ def test_bmp_textures_bit_exact(golden, oracle_for, name):
     assert np.array_equal(bits(out), bits(g[name]))
 
 
-@pytest.mark.parametrize("scene", ["sample", "competition", "bunny"])
+@pytest.mark.parametrize("scene", ["sample", "competition", "bunny", "cones"])
 def test_rays_bit_exact(golden, oracle_for, scene):
     g = golden("rays_" + scene)
     o = oracle_for(scene)
@@ -58,7 +58,8 @@ def test_rays_bit_exact(golden, oracle_for, scene):
 
 
 @pytest.mark.parametrize("name", ["sample_320x210", "competition_256x192", "bunny_160x120", "sample_160x105_spp16",
-                                  "competition_96x72_spp16", "sample_160x105_depth0", "competition_100x70_depth1"])
+                                  "competition_96x72_spp16", "sample_160x105_depth0", "competition_100x70_depth1",
+                                  "cones_320x240", "cones_150x110_spp16"])
 def test_render_bit_exact(golden, oracle_for, name):
     g = golden("render_" + name)
     p = render_params(g)
