@@ -174,3 +174,25 @@ def test_stress_lattice_against_oracle(oracle_for):
     assert st["n_triangles"] == 9 * 68202
     assert ids >= 0.9999 and frac >= 0.999 and psnr >= 50.0
     assert st["queue_overflow"] == 0
+
+
+def test_cpp_main_renders_what_the_c_abi_renders(tmp_path):
+    """raytracer_amd/host/raytracer_hip -- the reference's main() restated on the kept C++ surface (scene function ->
+    globals -> render() -> Image -> PPM) -- must write exactly the image rt_render returns for the same parameters"""
+    import os
+    import subprocess
+    exe = os.path.join(N.PKG_DIR, "host", "raytracer_hip")
+    out = str(tmp_path / "cones.ppm")
+    subprocess.run([exe, "--scene", "cones", "--width", "96", "--height", "64", "--spp", "4", "--depth", "3",
+                    "--assets", N.ASSET_DIR, out], check=True, timeout=120)
+    raw = open(out, "rb").read()
+    head = raw.split(b"\n", 3)
+    assert head[0] == b"P6" and head[1] == b"96 64" and head[2] == b"255"
+    img = np.frombuffer(head[3], np.uint8).reshape(64, 96, 3)
+    ref = renderer_for("cones").render(96, 64, spp=4, max_depth=3)
+    assert np.array_equal(img, ref["rgb8"])
+    # the reference's own ASCII P3 layout on request
+    out3 = str(tmp_path / "cones_p3.ppm")
+    subprocess.run([exe, "--scene", "cones", "--width", "32", "--height", "16", "--p3", "--assets", N.ASSET_DIR, out3], check=True, timeout=120)
+    tok = open(out3).read().split()
+    assert tok[:4] == ["P3", "32", "16", "255"] and len(tok) == 4 + 32 * 16 * 3
