@@ -133,7 +133,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / max(a.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "reference scene assets (meshes/*.obj), synthetic camera samples",
             "config": {"workload": f"{a.scene} scene {W}x{H} @{a.spp}spp depth {a.depth}", "triangles": scene.n_triangles,
-                       "tiles": n_tiles, "parallelism": f"tiles%{world}", "chunk_samples": a.chunk or (1 << 24)},
+                       "tiles": n_tiles, "parallelism": f"tiles%{world}", "chunk_samples": a.chunk or (1 << 26)},
             "primary_samples_per_s": prim_all / dt, "rays_per_primary": rays_all / max(prim_all, 1.0),
             "ms_per_frame": dt / max(a.steps, 1) * 1e3, "bvh": {"nodes": st["bvh_nodes"], "depth": st["bvh_depth"]},
         }

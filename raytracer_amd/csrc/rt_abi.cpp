@@ -259,10 +259,14 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     int64_t n_local = 0, n_total = 0;
     rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, &n_total);
     const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
-    size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 24;
+    size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 26;
     chunk_samples = std::min<size_t>(chunk_samples, RT_SAMPLE_MASK);
     size_t chunk_tiles = std::max<size_t>(1, chunk_samples / per_tile);
     chunk_tiles = std::min<size_t>(chunk_tiles, std::max<int64_t>(n_local, 1));
+    if (n_local > 0) {  // equal chunks: no small straggler at the end of the frame
+        const size_t nc = ((size_t)n_local + chunk_tiles - 1) / chunk_tiles;
+        chunk_tiles = ((size_t)n_local + nc - 1) / nc;
+    }
     if (chunk_tiles * per_tile > RT_SAMPLE_MASK) return fail("spp too large for one tile per chunk");
     if (ensureWorkspace(ctx, chunk_tiles * per_tile, p->max_depth, (int)ctx->lights.size())) return 1;
     const size_t n_chunks = n_local ? (size_t)((n_local + chunk_tiles - 1) / chunk_tiles) : 0;

@@ -9,5 +9,5 @@ python - <<PY
 import json
 d=json.load(open("gpurun_out/$tag/bench.json"))
 print("Mrays/s", round(d["value"]), "ms/frame", round(d["ms_per_step"],1), d.get("kernel_ms"))
-r=d.get("roofline",{}); print({k:r.get(k) for k in ("kernel","achieved","frac","nodes_per_ray","tris_per_ray")}, d.get("roofline_valu",{}).get("frac"))
+r=d.get("roofline",{}); print({k:r.get(k) for k in ("kernel","achieved","frac","records_per_ray","traffic")}, d.get("roofline_valu",{}).get("frac"))
 PY
