@@ -761,6 +761,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
     // waves per frame would serialise), everybody derives its slot from the block base.  Double-buffered by loop
     // parity so that one barrier pair per iteration suffices.
     __shared__ uint32_t s_cnt[2][2][RT_BLOCK / 64];
+    __shared__ uint32_t s_lit[2][RT_BLOCK / 64][RT_MAX_LIGHTS];  // shadow rays per (wave, light) of the iteration
     __shared__ uint32_t s_base[2][2];
     const int buf = level & 1, nbuf = buf ^ 1;
     const uint32_t n = min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
@@ -903,7 +904,11 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
         RT_PROF_MARK(1)
         // ---- block-aggregated reservation of shadow-ray and next-level slots ----
         uint32_t totS = 0;
-        for (int l = 0; l < nlights; l++) totS += (uint32_t)__popcll(__ballot((litmask >> l) & 1u));
+        for (int l = 0; l < nlights; l++) {
+            const uint32_t c = (uint32_t)__popcll(__ballot((litmask >> l) & 1u));
+            if (lane == 0) s_lit[parity][wave][l] = c;
+            totS += c;
+        }
         const unsigned long long mRefl = __ballot(emitRefl), mRefr = __ballot(emitRefr);
         const uint32_t totR = (uint32_t)(__popcll(mRefl) + __popcll(mRefr));
         if (lane == 0) {
@@ -919,17 +924,21 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
         }
         __syncthreads();
         uint32_t offS = s_base[parity][0], offR = s_base[parity][1];
-        for (uint32_t w = 0; w < wave; w++) {
-            offS += s_cnt[parity][0][w];
-            offR += s_cnt[parity][1][w];
-        }
+        for (uint32_t w = 0; w < wave; w++) offR += s_cnt[parity][1][w];
 
         RT_PROF_MARK(2)
-        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  Inside the
-        // wave's slab the rays are light-major, so a batch of shadow rays towards one light stays coherent for k_any.
+        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  The BLOCK's
+        // slab is light-major (all its rays towards light 0, then light 1, ...; waves in order inside a light), so k_any
+        // batches hold rays towards one light from neighbouring hits: coherent walks.
         for (int l = 0; l < nlights; l++) {
             const bool lit = (litmask >> l) & 1u;
             const unsigned long long mask = __ballot(lit);
+            uint32_t lightTotal = 0, before = 0;  // rays of the block towards light l, and those of the waves before this one
+            for (uint32_t w = 0; w < RT_BLOCK / 64; w++) {
+                const uint32_t c = s_lit[parity][w][l];
+                before += w < wave ? c : 0u;
+                lightTotal += c;
+            }
             if (lit) {
                 const V3 lp = ld3(sc.lights[l].pos), lc = ld3(sc.lights[l].color);
                 const V3 ld = normalize(lp - P);                     // main.cpp:97
@@ -957,7 +966,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
                 c = c * directScale;   // x * 1.0f is exact when no scaling applies
                 c = c * directScale2;
                 c = c * weight;
-                const uint32_t slot = offS + maskRankBelow(mask);
+                const uint32_t slot = offS + before + maskRankBelow(mask);
                 if (slot < q.shadow_cap) {  // 32-byte record: point + (sample, light), pending colour (rtShadowRay rebuilds the ray)
                     q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | ((uint32_t)l << 28)));
                     q.shC[slot] = make_float4(c.x, c.y, c.z, 0.0f);
@@ -965,7 +974,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                 }
             }
-            offS += (uint32_t)__popcll(mask);
+            offS += lightTotal;
         }
         RT_PROF_MARK(3)
         // ---- next-level rays, lane-major so that a reflection/refraction pair stays adjacent ----
