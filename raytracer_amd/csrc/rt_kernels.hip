@@ -38,25 +38,35 @@ RT_DEV uint32_t waveReserve(uint32_t *counter, uint32_t total) {
 // descent, the other hit children pushed far-first) or runs the reference's exact triangle test.
 struct RtTraversalStats { uint32_t nodes, tris; };
 
+typedef __attribute__((address_space(3))) uint32_t RtLdsWord;  // typed LDS pointer: pops stay ds_read, never flat loads
+// The stack's bases are WAVE-uniform (SGPRs); the lane's own column is re-derived at each push/pop with two mbcnt
+// instructions.  Holding per-lane base pointers (1 + 2 VGPRs) across the walk made the allocator spill them at 64
+// VGPRs and reload them from scratch before every LDS access.
+RT_DEV uint32_t laneNow() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 struct RtStack {          // per-lane stack: the first `lds_entries` live in LDS ([entry][lane], conflict free),
-    uint32_t *lds;        // deeper ones in a global spill area ([entry][grid thread], coalesced)
-    uint32_t *spill;
+    RtLdsWord *lds;       // deeper ones in a global spill area ([entry][grid thread], coalesced); both point at the
+    uint32_t *spill;      // wave's lane 0
     uint32_t spill_stride;
     int lds_entries;
 };
 RT_DEV void rtPush(const RtStack &s, int &sp, uint32_t v) {
-    if (sp < s.lds_entries) s.lds[sp * RT_BLOCK] = v;
-    else s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride] = v;
+    if (sp < s.lds_entries) s.lds[sp * RT_BLOCK + laneNow()] = v;
+    else s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride + laneNow()] = v;
     sp++;
 }
 RT_DEV uint32_t rtPop(const RtStack &s, int &sp) {  // requires sp > 0
     --sp;
-    return sp < s.lds_entries ? s.lds[sp * RT_BLOCK] : s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride];
+    return sp < s.lds_entries ? s.lds[sp * RT_BLOCK + laneNow()] : s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride + laneNow()];
 }
 RT_DEV RtStack rtMakeStack(uint32_t *lds_base, uint32_t *spill, int lds_entries) {
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);  // first thread of this wave
     RtStack s;
-    s.lds = lds_base + threadIdx.x;
-    s.spill = spill + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    s.lds = (RtLdsWord *)(lds_base + wave0);
+    s.spill = spill + (size_t)blockIdx.x * RT_BLOCK + wave0;
     s.spill_stride = gridDim.x * RT_BLOCK;
     s.lds_entries = lds_entries;
     return s;
