@@ -118,7 +118,11 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     if (samples <= ctx->ws_samples && fanout <= ctx->ws_fanout && n_lights <= ctx->ws_lights) return 0;
     samples = std::max(samples, ctx->ws_samples);
     const int fo = std::max(fanout, ctx->ws_fanout), nl = std::max(n_lights, ctx->ws_lights);
-    const size_t ray_cap = samples * fo, sh_cap = ray_cap * nl;
+    // worst case of the deepest level, plus what k_shade's wave-private slabs may leave unused (one partly filled slab
+    // per wave and queue, one slot per slab where a reflection/refraction pair met its end)
+    const size_t waves = (size_t)rtShadeWaves(ctx->cfg);
+    const size_t ray_cap = samples * fo + waves * RT_SLAB_MAX + samples * fo / 64 + 128;
+    const size_t sh_cap = samples * fo * nl + waves * nl * RT_SLAB_MAX;
     if (ray_cap >= (1ull << 32) || sh_cap >= (1ull << 32)) return fail("chunk too large: queue capacity exceeds 2^32 entries");
     for (int k = 0; k < 2; k++) {
         if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
@@ -127,7 +131,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
     if (ctx->d_accum.alloc(samples * 3)) return 1;
     if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
-    if (ctx->d_resid.alloc(sh_cap)) return 1;  // sh_cap >= ray_cap
+    if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
     ctx->ws_samples = samples;
     ctx->ws_fanout = fo;
     ctx->ws_lights = nl;
@@ -184,7 +188,8 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
         st->rays_closest += c[RT_CNT_RAYS(d)];
         st->rays_shadow += c[RT_CNT_SHADOW(d)];
     }
-    st->rays_closest -= c[RT_CNT_INVALID];  // level-0 slots of pixels outside the image are not rays
+    st->rays_closest -= c[RT_CNT_INVALID];  // slots of pixels outside the image and unused slab slots are not rays
+    st->rays_shadow -= c[RT_CNT_SHADOW_HOLES];
     st->shadow_culled += c[RT_CNT_CULLED];
     st->hits_shaded += c[RT_CNT_SHADED];
     st->queue_overflow += c[RT_CNT_OVERFLOW];
@@ -206,7 +211,7 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
 void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
-               bool stats, KernelTimer &kt, rt_stats *st, bool level0_traced = false) {
+               bool stats, KernelTimer &kt, rt_stats *st, uint64_t level0_rays, bool level0_traced = false) {
     for (int level = 0; level <= max_depth; level++) {
         if (!(level == 0 && level0_traced)) {  // each level's queue is claimed once (dynamic fetch counters)
             kt.begin(1);
@@ -214,7 +219,7 @@ void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, 
             kt.end();
         }
         kt.begin(2);
-        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles, stats);
+        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles, stats, level0_rays << level);
         kt.end();
         kt.begin(3);
         rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
@@ -295,7 +300,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         kt.begin(0);
         rtLaunchGenPrimary(cfg, f, ctx->q, tile0, ntiles);
         kt.end();
-        runLevels(ctx, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st);
+        runLevels(ctx, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)ntiles * per_tile);
         kt.begin(4);
         rtLaunchResolve(cfg, f, ctx->q, tile0, ntiles, d_rgb8, d_rgbf);
         kt.end();
@@ -710,7 +715,7 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
         // level 0 closest hit first: the hit records of the batch are reported from it
         rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, false);
         if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
-        runLevels(ctx, cfg, depth, 1, 0, nullptr, false, kt, st, true);
+        runLevels(ctx, cfg, depth, 1, 0, nullptr, false, kt, st, m, true);
         rtLaunchBatchColors(cfg, ctx->q, m, d_col.p);
         std::vector<uint32_t> hc(RT_CNT_WORDS);
         e = hipStreamSynchronize(cfg.stream);

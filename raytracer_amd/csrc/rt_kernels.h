@@ -20,7 +20,9 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats);
 void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats);
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
-                   uint32_t tile0, uint32_t *primid_tiles, bool prof);
+                   uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs);
+// waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)
+inline int rtShadeWaves(const RtLaunchCfg &cfg) { return cfg.num_cus * RT_SHADE_BLOCKS_PER_CU * (RT_BLOCK / 64); }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles);
 void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,

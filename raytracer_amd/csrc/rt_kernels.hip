@@ -16,7 +16,6 @@
 #include "rt_device.h"
 #include "rt_kernels.h"
 
-#define RT_BLOCK 256
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave-level helpers
@@ -462,7 +461,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             }
             if (ANY && fin) C = q.shC[old_i];
             if (fin) writeResult(old_i, old_sample, C);
-            if (take) {
+            if (take && !(ANY && __float_as_uint(A.w) == RT_SHADOW_HOLE)) {  // (holes: unused slots of k_shade's slabs)
                 float ldist = 0.0f;
                 if (ANY) {
                     rtShadowRay(sc, A, w.r, ldist, sample);
@@ -565,6 +564,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
         A = ANY ? q.shA[i] : q.rayA[buf][i];
         if (!ANY) B = q.rayB[buf][i];
     }
+    const bool hole = ANY && __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
     uint32_t sample = __float_as_uint(B.w);
     float ldist = 0.0f;
     if (ANY) {
@@ -574,7 +574,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
         w.r.d = v3(B.x, B.y, B.z);
     }
     rtInitWalk(sc, w, root_ref);
-    bool alive = valid;
+    bool alive = valid && !hole;
     if (ANY) {
         w.best_t = ldist;  // light distance
         w.best_id = RT_ID_MISS;
@@ -765,29 +765,34 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t roo
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
 template <bool PROF>
 __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
-                                                   uint32_t tile0, uint32_t *primid_tiles) {
-    // queue reservation is aggregated per BLOCK: waves post their counts in LDS, one lane per queue does the global
-    // atomic (a returning atomic on one address retires every ~10 ns chip-wide, so per-wave reservations of ~40 M
-    // waves per frame would serialise), everybody derives its slot from the block base.  Double-buffered by loop
-    // parity so that one barrier pair per iteration suffices.
-    __shared__ uint32_t s_cnt[2][2][RT_BLOCK / 64];
-    __shared__ uint32_t s_lit[2][RT_BLOCK / 64][RT_MAX_LIGHTS];  // shadow rays per (wave, light) of the iteration
-    __shared__ uint32_t s_base[2][2];
+                                                   uint32_t tile0, uint32_t *primid_tiles, uint32_t slab) {
+    // Output slots come from WAVE-PRIVATE slabs: a wave reserves `slab` consecutive slots of the shadow queue per light
+    // (and of the next level's ray queue) with one atomic and fills them over its next iterations -- no barrier, no
+    // per-iteration atomic, and a slab holds rays towards ONE light, which keeps k_any's batches coherent.  Cursor and
+    // end of the slab for light l live in lane l of curv/endv, those of the ray slab in lane RT_MAX_LIGHTS.  What a
+    // wave leaves unused at the end is marked as holes (shadow: w = RT_SHADOW_HOLE; rays: RT_FLAG_INVALID), which the
+    // trace kernels skip; holes are counted so that the ray statistics stay exact.
+    uint32_t curv = 0, endv = 0, holesS = 0, holesR = 0;
+    const uint32_t slabS = slab, slabR = max(slab, 128u);  // one iteration emits at most 64 shadow rays per light, 128 rays
     const int buf = level & 1, nbuf = buf ^ 1;
     const uint32_t n = min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
-    const uint32_t rounded = (n + (RT_BLOCK - 1)) & ~(uint32_t)(RT_BLOCK - 1);  // uniform trip count per block
+    // A wave shades SEGMENTS of consecutive queue entries (consecutive entries are neighbouring samples / hits), so the
+    // rays it appends to a slab leave neighbouring points towards one light.  Segments are dealt round-robin to the
+    // waves; their length adapts to the queue so that every wave still gets several.
+    const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64), gwave = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t seg = min(max((n / (nwaves * 8u)) & ~63u, 64u), RT_SHADE_SEGMENT);
     const int remaining = max_depth - level;
-    const uint32_t wave = threadIdx.x >> 6, lane = laneId();
+    const uint32_t lane = laneId();
     const int nlights = sc.n_lights;
     uint32_t culled = 0, shaded = 0;
     // PROF build: shader clocks per section, summed over waves: [0] loads + hit reconstruction, [1] material, light
-    // culling, textures, ambient, bounce set-up, [2] queue reservation (barriers + atomics), [3] shadow-ray emission,
+    // culling, textures, ambient, bounce set-up, [2] (unused since the slabs), [3] shadow-ray emission,
     // [4] next-level emission, [5] iterations
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
 #define RT_PROF_MARK(k) if (PROF) { tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tp; tp = tn; }
-    int parity = 0;
-    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < rounded; i += gridDim.x * RT_BLOCK, parity ^= 1) {
-        bool active = i < n;
+    for (uint64_t seg0 = (uint64_t)gwave * seg; seg0 < n; seg0 += (uint64_t)nwaves * seg)
+    for (uint32_t i = (uint32_t)seg0 + lane, segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n); i - lane < segEnd; i += 64) {
+        bool active = i < segEnd;
         float2 hrec = make_float2(0.0f, __uint_as_float(RT_ID_MISS));
         float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_INVALID));
         if (active) {
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             }
         }
 
-        if (level == 0 && i < n) {
+        if (level == 0 && i < segEnd) {
             // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
             // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.
             long long *acc = q.accum + 3ull * sample;
@@ -912,42 +917,27 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             acc[2] = rtToFixed(amb0.z);
         }
         RT_PROF_MARK(1)
-        // ---- block-aggregated reservation of shadow-ray and next-level slots ----
-        uint32_t totS = 0;
-        for (int l = 0; l < nlights; l++) {
-            const uint32_t c = (uint32_t)__popcll(__ballot((litmask >> l) & 1u));
-            if (lane == 0) s_lit[parity][wave][l] = c;
-            totS += c;
-        }
-        const unsigned long long mRefl = __ballot(emitRefl), mRefr = __ballot(emitRefr);
-        const uint32_t totR = (uint32_t)(__popcll(mRefl) + __popcll(mRefr));
-        if (lane == 0) {
-            s_cnt[parity][0][wave] = totS;
-            s_cnt[parity][1][wave] = totR;
-        }
-        __syncthreads();
-        if (threadIdx.x < 2) {
-            uint32_t sum = 0;
-            for (int w = 0; w < RT_BLOCK / 64; w++) sum += s_cnt[parity][threadIdx.x][w];
-            uint32_t *ctr = q.counters + (threadIdx.x == 0 ? RT_CNT_SHADOW(level) : RT_CNT_RAYS(level + 1));
-            s_base[parity][threadIdx.x] = sum ? atomicAdd(ctr, sum) : 0u;
-        }
-        __syncthreads();
-        uint32_t offS = s_base[parity][0], offR = s_base[parity][1];
-        for (uint32_t w = 0; w < wave; w++) offR += s_cnt[parity][1][w];
-
         RT_PROF_MARK(2)
-        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray.  The BLOCK's
-        // slab is light-major (all its rays towards light 0, then light 1, ...; waves in order inside a light), so k_any
-        // batches hold rays towards one light from neighbouring hits: coherent walks.
+        // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray ----
         for (int l = 0; l < nlights; l++) {
             const bool lit = (litmask >> l) & 1u;
             const unsigned long long mask = __ballot(lit);
-            uint32_t lightTotal = 0, before = 0;  // rays of the block towards light l, and those of the waves before this one
-            for (uint32_t w = 0; w < RT_BLOCK / 64; w++) {
-                const uint32_t c = s_lit[parity][w][l];
-                before += w < wave ? c : 0u;
-                lightTotal += c;
+            if (!mask) continue;  // wave-uniform
+            const uint32_t c = (uint32_t)__popcll(mask), rank = maskRankBelow(mask);
+            uint32_t cur = __builtin_amdgcn_readlane(curv, l), end = __builtin_amdgcn_readlane(endv, l);
+            const uint32_t room = end - cur;
+            uint32_t slot = cur + rank;
+            if (c > room) {  // the slab is used up to its last slot, the rest of the rays opens the next one
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(level), slabS);
+                if (rank >= room) slot = nbase + (rank - room);
+                cur = nbase + (c - room);
+                end = nbase + slabS;
+            } else {
+                cur += c;
+            }
+            if (lane == (uint32_t)l) {
+                curv = cur;
+                endv = end;
             }
             if (lit) {
                 const V3 lp = ld3(sc.lights[l].pos), lc = ld3(sc.lights[l].color);
@@ -972,24 +962,48 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
                     const float specular = smax(0.0f, powf(dot(hv, ns), 4 * shiny));
                     spec = attenuation * lc * mspec * specular;
                 }
-                V3 c = diffusion + spec;
-                c = c * directScale;   // x * 1.0f is exact when no scaling applies
-                c = c * directScale2;
-                c = c * weight;
-                const uint32_t slot = offS + before + maskRankBelow(mask);
+                V3 c3 = diffusion + spec;
+                c3 = c3 * directScale;   // x * 1.0f is exact when no scaling applies
+                c3 = c3 * directScale2;
+                c3 = c3 * weight;
                 if (slot < q.shadow_cap) {  // 32-byte record: point + (sample, light), pending colour (rtShadowRay rebuilds the ray)
                     q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | ((uint32_t)l << 28)));
-                    q.shC[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+                    q.shC[slot] = make_float4(c3.x, c3.y, c3.z, 0.0f);
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                 }
             }
-            offS += lightTotal;
         }
         RT_PROF_MARK(3)
-        // ---- next-level rays, lane-major so that a reflection/refraction pair stays adjacent ----
-        {
-            uint32_t slot = offR + maskRankBelow(mRefl) + maskRankBelow(mRefr);
+        // ---- next-level rays, lane-major so that a reflection/refraction pair stays adjacent (also across slabs) ----
+        const unsigned long long mRefl = __ballot(emitRefl), mRefr = __ballot(emitRefr);
+        if (mRefl | mRefr) {  // wave-uniform
+            const uint32_t k = (emitRefl ? 1u : 0u) + (emitRefr ? 1u : 0u);
+            const uint32_t off = maskRankBelow(mRefl) + maskRankBelow(mRefr);
+            const uint32_t c = (uint32_t)(__popcll(mRefl) + __popcll(mRefr));
+            uint32_t cur = __builtin_amdgcn_readlane(curv, RT_MAX_LIGHTS), end = __builtin_amdgcn_readlane(endv, RT_MAX_LIGHTS);
+            const uint32_t room = end - cur;
+            uint32_t slot = cur + off;
+            if (c > room) {
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_RAYS(level + 1), slabR);
+                // first lane whose rays do not fit any more: it and the lanes after it move to the new slab
+                const unsigned long long nofit = __ballot(k > 0 && off + k > room);
+                const uint32_t f = (uint32_t)__ffsll((long long)nofit) - 1u;
+                const uint32_t off_f = __builtin_amdgcn_readlane(off, f);
+                if (lane >= f) slot = nbase + (off - off_f);
+                if (lane == f && room > off_f) {  // a pair met the slab's last slot: that slot becomes a hole
+                    if (end - 1 < q.ray_cap) q.rayB[nbuf][end - 1] = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
+                    holesR++;
+                }
+                cur = nbase + (c - off_f);
+                end = nbase + slabR;
+            } else {
+                cur += c;
+            }
+            if (lane == RT_MAX_LIGHTS) {
+                curv = cur;
+                endv = end;
+            }
             if (emitRefl) {
                 if (slot < q.ray_cap) {
                     const V3 ro = P + RT_EPSILON * reflDir;  // main.cpp:155
@@ -1016,6 +1030,17 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
         RT_PROF_MARK(4)
         if (PROF) prof[5]++;
     }
+    // ---- what is left of the wave's slabs becomes holes ----
+    for (int l = 0; l < nlights; l++) {
+        const uint32_t cur = __builtin_amdgcn_readlane(curv, l), end = min(__builtin_amdgcn_readlane(endv, l), q.shadow_cap);
+        for (uint32_t sl = cur + lane; sl < end; sl += 64) q.shA[sl] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_SHADOW_HOLE));
+        if (lane == 0 && end > cur) holesS += end - cur;
+    }
+    {
+        const uint32_t cur = __builtin_amdgcn_readlane(curv, RT_MAX_LIGHTS), end = min(__builtin_amdgcn_readlane(endv, RT_MAX_LIGHTS), q.ray_cap);
+        for (uint32_t sl = cur + lane; sl < end; sl += 64) q.rayB[nbuf][sl] = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
+        if (lane == 0 && end > cur) holesR += end - cur;
+    }
     if (PROF && lane == 0) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + RT_CNT_PROF_SHADE);
         for (int k = 0; k < 6; k++) atomicAdd(dst + k, prof[k]);
@@ -1025,10 +1050,14 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
     for (int off = 32; off > 0; off >>= 1) {
         culled += __shfl_down(culled, off);
         shaded += __shfl_down(shaded, off);
+        holesS += __shfl_down(holesS, off);
+        holesR += __shfl_down(holesR, off);
     }
     if (lane == 0) {
         if (culled) atomicAdd(q.counters + RT_CNT_CULLED, culled);
         if (shaded) atomicAdd(q.counters + RT_CNT_SHADED, shaded);
+        if (holesS) atomicAdd(q.counters + RT_CNT_SHADOW_HOLES, holesS);
+        if (holesR) atomicAdd(q.counters + RT_CNT_INVALID, holesR);  // ray-queue holes are invalid slots like those of k_gen_primary
     }
 }
 
@@ -1206,9 +1235,13 @@ void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref
     launchTrace<true>(cfg, sc, root_ref, q, level, stats);
 }
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
-                   uint32_t tile0, uint32_t *primid_tiles, bool prof) {
-    if (prof) hipLaunchKernelGGL(k_shade<true>, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles);
+                   uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs) {
+    // slab: at most an eighth of what a wave can receive, so that the unused tails stay a small part of the queues
+    const uint64_t waves = (uint64_t)rtShadeWaves(cfg);
+    uint32_t slab = 64;
+    while (slab < RT_SLAB_MAX && (uint64_t)slab * 16 * waves <= max_inputs) slab <<= 1;
+    if (prof) hipLaunchKernelGGL(k_shade<true>, dim3(gridFor(cfg, RT_SHADE_BLOCKS_PER_CU)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(gridFor(cfg, RT_SHADE_BLOCKS_PER_CU)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
 }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles) {

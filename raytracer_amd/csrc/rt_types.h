@@ -140,7 +140,12 @@ struct RtFrameDev {
 // ray flags packed above the sample index (28 bits of sample index)
 #define RT_SAMPLE_MASK 0x0FFFFFFFu
 #define RT_FLAG_HAS_REFR_SIBLING 0x10000000u  // reflection ray whose refraction sibling sits in the next slot
-#define RT_FLAG_INVALID 0x20000000u           // level-0 slot of a pixel outside the image: traced as a miss, never shaded
+#define RT_SHADOW_HOLE 0xFFFFFFFFu            // w of a shadow record that holds no ray (unused slot of a k_shade slab)
+#define RT_SLAB_MAX 1024u                    // slots a k_shade wave reserves at a time, per light / for the next level
+#define RT_SHADE_BLOCKS_PER_CU 4
+#define RT_SHADE_SEGMENT 1024u                // consecutive queue entries a k_shade wave shades before it jumps
+#define RT_BLOCK 256                         // threads per block of every kernel
+#define RT_FLAG_INVALID 0x20000000u           // slot of a pixel outside the image or unused slab slot: traced as a miss, never shaded
 
 // Wavefront queues of one chunk (device pointers).  Rays: A = (origin.xyz, weight), B = (direction.xyz, sample|flags),
 // R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (shaded point, sample | light << 28),
@@ -176,6 +181,7 @@ struct RtQueues {
 #define RT_CNT_PROF_SHADE (72 * RT_CNT_STRIDE)               // 6 x u64 wave-time breakdown of k_shade (stats build)
 #define RT_CNT_PROF_PACKET_CLOSEST (73 * RT_CNT_STRIDE)      // 8 x u64 packet statistics of k_packet<closest> (stats build)
 #define RT_CNT_PROF_PACKET_ANY (74 * RT_CNT_STRIDE)          // same for shadow packets
+#define RT_CNT_SHADOW_HOLES (75 * RT_CNT_STRIDE)             // unused slab slots of the shadow queues (not rays)
 #define RT_CNT_RESID_CLOSEST(d) ((76 + (d)) * RT_CNT_STRIDE) // rays of level d handed to the per-lane closest-hit kernel
 #define RT_CNT_RESID_ANY(d) ((92 + (d)) * RT_CNT_STRIDE)     // same for shadow rays
 #define RT_CNT_PWORK_CLOSEST(d) ((108 + (d)) * RT_CNT_STRIDE) // next unclaimed packet batch of level d (packet kernels)
