@@ -9,8 +9,8 @@
 //   k_assemble      tile-major rank buffers -> row-major image (multi-GPU gather epilogue)
 //   k_hitinfo / k_eval_texture / k_eval_perlin   test hooks of the C ABI
 //
-// Queues are compacted with 64-wide ballots (mbcnt gives the lane offset inside the wave) and reserved with ONE atomic
-// per 256-thread block and queue.
+// Queues are compacted with 64-wide ballots (mbcnt gives the lane offset inside the wave); k_shade's waves reserve
+// their output slots in slabs (one atomic per RT_SLAB_MAX slots), the unused remainder of a slab is flagged as holes.
 // Traversal keeps a per-lane stack in LDS, laid out [entry][lane] so that a wave's push/pop is conflict-free.
 #include <hip/hip_runtime.h>
 #include "rt_device.h"
@@ -821,7 +821,6 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
         V3 P = v3s(0), ns = v3s(0), view = v3s(0), normal = v3s(0), dcol = v3s(0), mspec = v3s(0), hT = v3s(0), hB = v3s(0);
         float weight = 0.0f, shiny = 0.0f, alpha_x = 1.0f, alpha_y = 1.0f, directScale = 1.0f, directScale2 = 1.0f;
         bool aniso = false;
-        uint32_t litmask = 0;  // bit l: light l faces the surface (is_shadowed's back-face test, main.cpp:44-46)
         bool emitRefl = false, emitRefr = false;
         V3 amb0 = v3s(0.0f);
         V3 reflDir = v3s(0), refrDir = v3s(0);
@@ -857,20 +856,14 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             if (hasRefl) directScale = 1 - m.reflection;
             if (hasRefr) directScale2 = 1 - m.refraction;
 
-            for (int l = 0; l < nlights; l++) {
-                const V3 ld = normalize(ld3(sc.lights[l].pos) - P);  // main.cpp:97
-                if (dot(normal, ld) < 0) culled++;
-                else litmask |= 1u << l;
-            }
-            if (litmask) {
-                // texture and roughness are light-independent: evaluated once (the reference re-evaluates per light)
-                dcol = m.texture != RT_TEX_NONE ? rtEvalTexture(sc, m.texture, h.uv) : ld3(m.diffuse);
-                shiny = m.shininess;
-                if (m.has_img_texture) {  // main.cpp:116-117, double pow
-                    const double rough = (double)rtEvalTexture(sc, m.roughness, h.uv).x;
-                    const double r2 = rough * rough;
-                    shiny = (float)((0.5 / (r2 * r2)) - 0.5);
-                }
+            // texture and roughness are light-independent: evaluated once (the reference re-evaluates them per light
+            // that faces the surface; a hit no light faces does not use them)
+            dcol = m.texture != RT_TEX_NONE ? rtEvalTexture(sc, m.texture, h.uv) : ld3(m.diffuse);
+            shiny = m.shininess;
+            if (m.has_img_texture) {  // main.cpp:116-117, double pow
+                const double rough = (double)rtEvalTexture(sc, m.roughness, h.uv).x;
+                const double r2 = rough * rough;
+                shiny = (float)((0.5 / (r2 * r2)) - 0.5);
             }
             // ambient term, added at every node and never scaled (main.cpp:207-211)
             V3 amb;
@@ -920,7 +913,11 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
         RT_PROF_MARK(2)
         // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray ----
         for (int l = 0; l < nlights; l++) {
-            const bool lit = (litmask >> l) & 1u;
+            // is_shadowed's back-face test (main.cpp:44-46): a light behind the surface casts no shadow ray
+            const V3 lp = ld3(sc.lights[l].pos), toL = lp - P;
+            const V3 ld = normalize(toL);                            // main.cpp:97
+            const bool lit = active && !(dot(normal, ld) < 0);
+            if (active && !lit) culled++;
             const unsigned long long mask = __ballot(lit);
             if (!mask) continue;  // wave-uniform
             const uint32_t c = (uint32_t)__popcll(mask), rank = maskRankBelow(mask);
@@ -940,9 +937,8 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
                 endv = end;
             }
             if (lit) {
-                const V3 lp = ld3(sc.lights[l].pos), lc = ld3(sc.lights[l].color);
-                const V3 ld = normalize(lp - P);                     // main.cpp:97
-                const float dl = length(lp - P);                     // :98
+                const V3 lc = ld3(sc.lights[l].color);
+                const float dl = length(toL);                        // :98
                 const float diffuse = smax(0.0f, dot(ld, ns));       // :104
                 const V3 hv = normalize(ld + view);                  // :106
                 const float distance = smax(0.1f, dl);               // :109
