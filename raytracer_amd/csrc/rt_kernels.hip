@@ -869,15 +869,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             V3 amb;
             if (m.has_img_texture) amb = ld3(sc.ambient) * 0.1f * rtEvalTexture(sc, m.occlusion, h.uv).x;
             else amb = ld3(sc.ambient) * ld3(m.ambient);
-            amb = amb * weight;
-            if (level == 0) {  // first contribution of the sample: stored below, together with the zeros of the misses
-                amb0 = amb;
-            } else {
-                unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
-                atomicAdd(acc + 0, (unsigned long long)rtToFixed(amb.x));
-                atomicAdd(acc + 1, (unsigned long long)rtToFixed(amb.y));
-                atomicAdd(acc + 2, (unsigned long long)rtToFixed(amb.z));
-            }
+            amb0 = amb * weight;  // level 0: first contribution of the sample, stored below together with the zeros of the misses
 
             if (hasRefl) {  // main.cpp:152-166
                 reflDir = rtReflect(-view, ns);
@@ -901,6 +893,32 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             }
         }
 
+        if (level > 0) {
+            // Ambient terms of levels >= 1 go to the accumulators by atomics, and the L2 atomic units are what they
+            // cost: the rays of one sample (a reflection/refraction pair, their children) sit in neighbouring lanes, so
+            // runs of equal samples inside a group of 8 lanes are summed first (in fixed point: same bits as separate
+            // atomics) and only the first lane of a run issues the atomics.
+            long long fx = active ? rtToFixed(amb0.x) : 0, fy = active ? rtToFixed(amb0.y) : 0, fz = active ? rtToFixed(amb0.z) : 0;
+            const uint32_t key = active ? sample : (RT_SAMPLE_MASK + 1u + lane);  // never equal to a neighbour's
+            const uint32_t pkey = __shfl_up(key, 1);
+            const bool head = (lane & 7u) == 0 || pkey != key;  // first lane of a run
+            const unsigned long long heads = __ballot(head);
+            for (int d = 1; d < 8; d <<= 1) {
+                const long long ox = __shfl_down(fx, d), oy = __shfl_down(fy, d), oz = __shfl_down(fz, d);
+                // lane + d belongs to this lane's run iff no run starts in (lane, lane + d]
+                if ((lane & 7u) + d < 8u && ((heads >> (lane + 1u)) & ((1ull << d) - 1ull)) == 0) {
+                    fx += ox;
+                    fy += oy;
+                    fz += oz;
+                }
+            }
+            if (active && head) {
+                unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
+                atomicAdd(acc + 0, (unsigned long long)fx);
+                atomicAdd(acc + 1, (unsigned long long)fy);
+                atomicAdd(acc + 2, (unsigned long long)fz);
+            }
+        }
         if (level == 0 && i < segEnd) {
             // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
             // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.
