@@ -30,6 +30,36 @@ RT_DEV uint32_t waveReserve(uint32_t *counter, uint32_t total) {
     return __builtin_amdgcn_readfirstlane(base);
 }
 
+// Adds (x, y, z) to the fixed-point accumulator of `sample` for every lane with `on`.  What these atomics cost is the
+// L2 atomic units' time per lane operation, and the rays of one sample (a reflection/refraction pair, their children,
+// the shadow rays those cast towards one light) sit in neighbouring queue slots, hence mostly in neighbouring lanes:
+// runs of equal samples inside a group of 8 lanes are summed first -- in fixed point, so the accumulator ends up with
+// the same bits as with separate atomics -- and only the first lane of a run issues the atomics.
+// All 64 lanes must call this together.
+RT_DEV void accumulateRuns(long long *accum, bool on, uint32_t sample, V3 c) {
+    const uint32_t lane = laneId();
+    long long fx = on ? rtToFixed(c.x) : 0, fy = on ? rtToFixed(c.y) : 0, fz = on ? rtToFixed(c.z) : 0;
+    const uint32_t key = on ? sample : (RT_SAMPLE_MASK + 1u + lane);  // never equal to a neighbour's
+    const uint32_t pkey = __shfl_up(key, 1);
+    const bool head = (lane & 7u) == 0 || pkey != key;  // first lane of a run
+    const unsigned long long heads = __ballot(head);
+    for (int d = 1; d < 8; d <<= 1) {
+        const long long ox = __shfl_down(fx, d), oy = __shfl_down(fy, d), oz = __shfl_down(fz, d);
+        // lane + d belongs to this lane's run iff no run starts in (lane, lane + d]
+        if ((lane & 7u) + d < 8u && ((heads >> (lane + 1u)) & ((1ull << d) - 1ull)) == 0) {
+            fx += ox;
+            fy += oy;
+            fz += oz;
+        }
+    }
+    if (on && head) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(accum) + 3ull * sample;
+        atomicAdd(acc + 0, (unsigned long long)fx);
+        atomicAdd(acc + 1, (unsigned long long)fy);
+        atomicAdd(acc + 2, (unsigned long long)fz);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // BVH traversal: 4-wide quantised nodes and triangle records in ONE array of 64-byte records (rt_types.h).  A step
 // fetches the record the lane's `cur` refers to -- four 16-byte loads issued by every lane of the wave together,
@@ -422,7 +452,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // conversions and atomics) would run once per ray with one or two lanes active.
     bool fin = false;
     auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
-        if (ANY) {
+        if (ANY) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
             atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
@@ -893,32 +923,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q
             }
         }
 
-        if (level > 0) {
-            // Ambient terms of levels >= 1 go to the accumulators by atomics, and the L2 atomic units are what they
-            // cost: the rays of one sample (a reflection/refraction pair, their children) sit in neighbouring lanes, so
-            // runs of equal samples inside a group of 8 lanes are summed first (in fixed point: same bits as separate
-            // atomics) and only the first lane of a run issues the atomics.
-            long long fx = active ? rtToFixed(amb0.x) : 0, fy = active ? rtToFixed(amb0.y) : 0, fz = active ? rtToFixed(amb0.z) : 0;
-            const uint32_t key = active ? sample : (RT_SAMPLE_MASK + 1u + lane);  // never equal to a neighbour's
-            const uint32_t pkey = __shfl_up(key, 1);
-            const bool head = (lane & 7u) == 0 || pkey != key;  // first lane of a run
-            const unsigned long long heads = __ballot(head);
-            for (int d = 1; d < 8; d <<= 1) {
-                const long long ox = __shfl_down(fx, d), oy = __shfl_down(fy, d), oz = __shfl_down(fz, d);
-                // lane + d belongs to this lane's run iff no run starts in (lane, lane + d]
-                if ((lane & 7u) + d < 8u && ((heads >> (lane + 1u)) & ((1ull << d) - 1ull)) == 0) {
-                    fx += ox;
-                    fy += oy;
-                    fz += oz;
-                }
-            }
-            if (active && head) {
-                unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
-                atomicAdd(acc + 0, (unsigned long long)fx);
-                atomicAdd(acc + 1, (unsigned long long)fy);
-                atomicAdd(acc + 2, (unsigned long long)fz);
-            }
-        }
+        if (level > 0) accumulateRuns(q.accum, active, sample, amb0);  // ambient term of the hit (levels >= 1)
         if (level == 0 && i < segEnd) {
             // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
             // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.
