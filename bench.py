@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two instrumented passes")
     ap.add_argument("--cpu-sample", default="160x120")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the gather even with one rank (rehearses the RCCL path on a 1-GPU box)")
     a = ap.parse_args()
 
     import numpy as np
@@ -85,7 +87,8 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -94,7 +97,7 @@ def main():
     W, H = a.width, a.height
     from raytracer_amd.dist import DistributedFrame, tile_counts
     n_tiles = tile_counts(W, H, 0, 1)[1]
-    df = DistributedFrame(r, W, H, rank, world, dev, dist)   # tile-major device buffers owned by torch
+    df = DistributedFrame(r, W, H, rank, world, dev, dist, force_collective=a.force_dist)   # tile-major device buffers owned by torch
     stream = torch.cuda.current_stream().cuda_stream
 
     def frame(collect=0):
@@ -102,7 +105,7 @@ def main():
         return df.render(stream=stream, spp=a.spp, max_depth=a.depth, chunk_samples=a.chunk, collect_stats=collect)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -119,7 +122,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tot = torch.tensor([dt, float(rays), float(prim)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -180,7 +183,7 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

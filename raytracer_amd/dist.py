@@ -27,13 +27,13 @@ def tiles_per_rank(width, height, world):
     return tile_counts(width, height, 0, world)[0]
 
 
-def gather_tiles(local, rank, world, dist=None):
+def gather_tiles(local, rank, world, dist=None, force_collective=False):
     """Gathers each rank-local tile-major tensor of `local` to rank 0.
 
     Returns, on rank 0, a list of tensors shaped [world, *local.shape] (the ranks' buffers back to back in rank order:
     the layout rt_assemble_tiles_device expects); None elsewhere.  world == 1 needs no process group."""
     import torch
-    if world == 1:
+    if world == 1 and not force_collective:
         return [t.unsqueeze(0) for t in local]
     out = []
     for t in local:
@@ -46,9 +46,10 @@ def gather_tiles(local, rank, world, dist=None):
 class DistributedFrame:
     """One rank's share of a frame on its GPU: render own tiles -> gather -> (rank 0) assemble the image."""
 
-    def __init__(self, renderer, width, height, rank, world, device, dist=None):
+    def __init__(self, renderer, width, height, rank, world, device, dist=None, force_collective=False):
         import torch
         self.r, self.W, self.H, self.rank, self.world, self.dist = renderer, width, height, rank, world, dist
+        self.force_collective = force_collective  # run the gather even with one rank (rehearsal of the RCCL path)
         self.per = tiles_per_rank(width, height, world)
         self.t8 = torch.zeros(self.per, TILE_PIXELS, 3, dtype=torch.uint8, device=device)
         self.tp = torch.zeros(self.per, TILE_PIXELS, dtype=torch.int32, device=device)
@@ -60,7 +61,7 @@ class DistributedFrame:
         """returns this rank's rt_stats dict; on rank 0 self.o8 / self.op hold the assembled image afterwards"""
         st = self.r.render_tiles_device(self.W, self.H, self.rank, self.world, self.t8.data_ptr(), 0, self.tp.data_ptr(),
                                         stream=stream, **kw)
-        g = gather_tiles([self.t8, self.tp], self.rank, self.world, self.dist)
+        g = gather_tiles([self.t8, self.tp], self.rank, self.world, self.dist, self.force_collective)
         if self.rank == 0:
             self.r.assemble_tiles_device(self.W, self.H, self.world, self.per, g[0].data_ptr(), 0, g[1].data_ptr(),
                                          self.o8.data_ptr(), 0, self.op.data_ptr(), stream=stream)
