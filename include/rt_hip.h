@@ -122,6 +122,8 @@ typedef struct rt_stats {
      * groups walked, [7] rays handed to the per-lane kernels */
     uint64_t prof_packet_closest[8];
     uint64_t prof_packet_any[8];
+    /* collect_stats & 1 only: the longest walk of a single ray, in steps (a launch cannot end before its longest ray) */
+    uint64_t max_walk_closest, max_walk_any;
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

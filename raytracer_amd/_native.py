@@ -58,6 +58,7 @@ class Stats(C.Structure):
         ("ms_resolve", C.c_double), ("launches_closest", C.c_uint64), ("launches_any", C.c_uint64),
         ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64), ("n_triangles", C.c_uint64),
         ("nodes_visited_any", C.c_uint64), ("tris_tested_any", C.c_uint64), ("bvh_max_stack", C.c_uint64), ("prof_closest", C.c_uint64 * 10), ("prof_any", C.c_uint64 * 10), ("prof_shade", C.c_uint64 * 6), ("prof_packet_closest", C.c_uint64 * 8), ("prof_packet_any", C.c_uint64 * 8),
+        ("max_walk_closest", C.c_uint64), ("max_walk_any", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -112,18 +112,32 @@ int bind(rt_context *ctx) {
     return 0;
 }
 
+// queue entries one chunk of `samples` primary samples can need: worst case of the deepest level, plus what k_shade's
+// wave-private slabs may leave unused (one partly filled slab per wave and queue, one slot per slab where a
+// reflection/refraction pair met its end)
+struct QueueSizes {
+    size_t ray_cap, sh_cap, bytes;
+    bool fits32;
+};
+QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl) {
+    QueueSizes z;
+    const size_t waves = (size_t)rtShadeWaves(ctx->cfg);
+    z.ray_cap = samples * fanout + waves * RT_SLAB_MAX + samples * fanout / 64 + 128;
+    z.sh_cap = samples * fanout * nl + waves * nl * RT_SLAB_MAX;
+    z.fits32 = z.ray_cap < (1ull << 32) && z.sh_cap < (1ull << 32);
+    z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8) + z.sh_cap * 32 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
+    return z;
+}
+
 int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights) {
     const int fanout = 1 << std::min(std::max(max_depth, 0), 4);  // rays of the deepest level per primary sample (worst case)
     n_lights = std::max(n_lights, 1);
     if (samples <= ctx->ws_samples && fanout <= ctx->ws_fanout && n_lights <= ctx->ws_lights) return 0;
     samples = std::max(samples, ctx->ws_samples);
     const int fo = std::max(fanout, ctx->ws_fanout), nl = std::max(n_lights, ctx->ws_lights);
-    // worst case of the deepest level, plus what k_shade's wave-private slabs may leave unused (one partly filled slab
-    // per wave and queue, one slot per slab where a reflection/refraction pair met its end)
-    const size_t waves = (size_t)rtShadeWaves(ctx->cfg);
-    const size_t ray_cap = samples * fo + waves * RT_SLAB_MAX + samples * fo / 64 + 128;
-    const size_t sh_cap = samples * fo * nl + waves * nl * RT_SLAB_MAX;
-    if (ray_cap >= (1ull << 32) || sh_cap >= (1ull << 32)) return fail("chunk too large: queue capacity exceeds 2^32 entries");
+    const QueueSizes z = queueSizes(ctx, samples, fo, nl);
+    const size_t ray_cap = z.ray_cap, sh_cap = z.sh_cap;
+    if (!z.fits32) return fail("chunk too large: queue capacity exceeds 2^32 entries");
     for (int k = 0; k < 2; k++) {
         if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
     }
@@ -197,6 +211,8 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
     st->nodes_visited += u64at(RT_CNT_NODES);
     st->tris_tested += u64at(RT_CNT_NODES + 2);
     st->nodes_visited_any += u64at(RT_CNT_ANY_NODES);
+    st->max_walk_closest = std::max<uint64_t>(st->max_walk_closest, c[RT_CNT_NODES + 4]);
+    st->max_walk_any = std::max<uint64_t>(st->max_walk_any, c[RT_CNT_ANY_NODES + 4]);
     st->tris_tested_any += u64at(RT_CNT_ANY_NODES + 2);
     for (int k = 0; k < 10; k++) {
         st->prof_closest[k] += u64at(RT_CNT_PROF_CLOSEST + 2 * k);
@@ -266,6 +282,17 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
     size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 26;
     chunk_samples = std::min<size_t>(chunk_samples, RT_SAMPLE_MASK);
+    if (p->chunk_samples <= 0) {
+        // default chunk: 64 Mi samples, halved until the queues' worst case fits 32-bit indices and 3/4 of the HBM
+        size_t free_b = 0, total_b = 0;
+        HIPOK(hipMemGetInfo(&free_b, &total_b));
+        const int fo = 1 << std::min(p->max_depth, 4), nl = std::max<int>(1, (int)ctx->lights.size());
+        while (chunk_samples > per_tile) {
+            const QueueSizes z = queueSizes(ctx, chunk_samples, fo, nl);
+            if (z.fits32 && z.bytes <= total_b / 4 * 3) break;
+            chunk_samples /= 2;
+        }
+    }
     size_t chunk_tiles = std::max<size_t>(1, chunk_samples / per_tile);
     chunk_tiles = std::min<size_t>(chunk_tiles, std::max<int64_t>(n_local, 1));
     if (n_local > 0) {  // equal chunks: no small straggler at the end of the frame
@@ -624,6 +651,8 @@ int rt_commit(rt_context *ctx) {
         int a = 1, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2) { ctx->cfg.packet_levels_closest = a; ctx->cfg.packet_levels_any = b; }
     }
+    ctx->dev.any_ordered = 0;  // tuning knob: shadow rays descend near-first (costs ~1 % on the competition scene)
+    if (const char *e = getenv("RT_ANY_ORDERED")) ctx->dev.any_ordered = atoi(e) != 0;
     ctx->cfg.analytic_bytes = (int)(units.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
     const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));

@@ -206,8 +206,9 @@ RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTr
         const bool hit = tn <= tf && ref[c] != 0xFFFFFFFFu;
         key[c] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;  // tn >= 0: bit order == value order
     }
-    if (ANY) {
-        // any-hit: order is irrelevant to the result -- enter the first hit child, push the others (no sort)
+    if (ANY && !sc.any_ordered) {
+        // any-hit: order is irrelevant to the result -- enter the first hit child, push the others (no sort).  In a
+        // large scene the order matters for the WORK: see any_ordered in rt_abi.cpp
         uint32_t next = RT_NODE_DONE;
 #pragma unroll
         for (int c = 3; c >= 0; c--)
@@ -451,6 +452,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // other lanes that finished meanwhile: written right away, the result code (a load, three fixed-point
     // conversions and atomics) would run once per ray with one or two lanes active.
     bool fin = false;
+    uint32_t walk = 0;  // STATS: steps of the lane's current ray (the longest walk bounds a launch's tail)
     auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
         if (ANY) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
@@ -470,6 +472,10 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     for (;;) {
         const unsigned long long idle = __ballot(!has);
         const unsigned long long tRefill = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (STATS && !has && walk) {
+            atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
+            walk = 0;
+        }
         if (idle && more) {
             if (pool_next >= pool_end) {
                 uint32_t base = 0;
@@ -536,12 +542,14 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             const unsigned long long tPhase = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             if (nNode >= nTri && nNode > 0) {
                 if (atNode) rtNodeStep<ANY, STATS>(sc, w, stk, st);
+                if (STATS && atNode) walk++;
                 if (STATS) {
                     prof[1] += __builtin_amdgcn_s_memtime() - tPhase;
                     prof[2]++;
                     prof[3] += nNode;
                 }
             } else if (nTri > 0) {
+                if (STATS && atTri) walk++;
                 if (atTri && rtTriStep<ANY, STATS>(sc, w, st)) has = false;  // occluded: the pending radiance is dropped
                 if (STATS) {
                     prof[4] += __builtin_amdgcn_s_memtime() - tPhase;
@@ -557,6 +565,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     }
     if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0));
     if (STATS) {
+        if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
         prof[7] = __builtin_amdgcn_s_memtime() - tStart;
         if (laneId() == 0) {

@@ -117,6 +117,7 @@ struct RtSceneDev {
     float ambient[3];
     float bound;                 // max |coordinate| of any node box (slab-test error bound, rt_kernels.hip)
     int32_t n_nodes, n_tris, n_spheres, n_planes, n_lights, n_objects, n_materials;
+    int32_t any_ordered;         // shadow rays descend near-first like closest-hit rays (chosen at rt_commit)
 };
 
 // Camera + image constants of the tile loop, precomputed on the host exactly as main.cpp:561-563 does.
@@ -172,7 +173,7 @@ struct RtQueues {
 #define RT_CNT_SHADED (33 * RT_CNT_STRIDE)
 #define RT_CNT_OVERFLOW (34 * RT_CNT_STRIDE)
 #define RT_CNT_INVALID (35 * RT_CNT_STRIDE)                  // level-0 slots outside the image (ragged edge tiles)
-#define RT_CNT_NODES (36 * RT_CNT_STRIDE)                    // u64 nodes at +0, u64 triangle tests at +2 (closest rays)
+#define RT_CNT_NODES (36 * RT_CNT_STRIDE)                    // u64 nodes at +0, u64 triangle tests at +2, u32 longest walk at +4 (closest rays)
 #define RT_CNT_ANY_NODES (37 * RT_CNT_STRIDE)                // same for shadow rays
 #define RT_CNT_PROF_CLOSEST (38 * RT_CNT_STRIDE)             // 10 x u64 wave-time breakdown of k_closest (stats build)
 #define RT_CNT_PROF_ANY (39 * RT_CNT_STRIDE)                 // same for k_any

@@ -14,3 +14,10 @@ for k in range(2):
 rays = st["rays_closest"] + st["rays_shadow"]
 print(f"{W}x{H} @{SPP}spp: {st['ms_total']:.1f} ms, {rays / st['ms_total'] / 1e3:.0f} Mrays/s, {rays / st['primary_samples']:.2f} rays/primary, "
       f"nodes {st['bvh_nodes']} depth {st['bvh_depth']} max_stack {st['bvh_max_stack']}")
+if os.environ.get("RT_STRESS_DETAIL", "1") != "0":
+    t = r.render(W, H, spp=SPP, want=(), collect_stats=2)["stats"]
+    print("kernel ms:", {k: round(t[k], 1) for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}, flush=True)
+    c = r.render(W, H, spp=SPP, want=(), collect_stats=1)["stats"]
+    print(f"records per closest ray: nodes {c['nodes_visited'] / c['rays_closest']:.2f} tris {c['tris_tested'] / c['rays_closest']:.2f}; "
+          f"per shadow ray: nodes {c['nodes_visited_any'] / c['rays_shadow']:.2f} tris {c['tris_tested_any'] / c['rays_shadow']:.2f}; "
+          f"rays closest {c['rays_closest']} shadow {c['rays_shadow']}; longest walk closest {c['max_walk_closest']} any {c['max_walk_any']}")
