@@ -82,6 +82,7 @@ struct rt_context {
     DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part
     DevBuf<RtNodeP> d_nodes_p;  // float-box form of the nodes (packet kernels)
     DevBuf<uint32_t> d_resid;   // queue indices of the rays the packet kernels hand to the per-lane kernels
+    DevBuf<uint2> d_split[2];   // work items of split any-hit walks (rt_kernels.hip), ping-pong by round
     DevBuf<RtTriShade> d_shade;
     DevBuf<RtSphere> d_spheres;
     DevBuf<RtPlane> d_planes;
@@ -146,6 +147,8 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     if (ctx->d_accum.alloc(samples * 3)) return 1;
     if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
     if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
+    const size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
+    if (ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) return 1;
     ctx->ws_samples = samples;
     ctx->ws_fanout = fo;
     ctx->ws_lights = nl;
@@ -162,6 +165,9 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     q.counters = ctx->d_counters.p;
     q.spill = ctx->d_spill.p;
     q.resid = ctx->d_resid.p;
+    q.split[0] = ctx->d_split[0].p;
+    q.split[1] = ctx->d_split[1].p;
+    q.split_cap = (uint32_t)split_cap;
     q.ray_cap = (uint32_t)ray_cap;
     q.shadow_cap = (uint32_t)sh_cap;
     return 0;
@@ -396,7 +402,7 @@ int rt_destroy(rt_context *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_nodes_p.release(); ctx->d_resid.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
+    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_nodes_p.release(); ctx->d_resid.release(); ctx->d_split[0].release(); ctx->d_split[1].release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
@@ -654,7 +660,8 @@ int rt_commit(rt_context *ctx) {
     ctx->dev.any_ordered = 0;  // tuning knob: shadow rays descend near-first (costs ~1 % on the competition scene)
     if (const char *e = getenv("RT_ANY_ORDERED")) ctx->dev.any_ordered = atoi(e) != 0;
     ctx->cfg.analytic_bytes = (int)(units.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
-    const int lds_per_block = entries * 256 * 4 + ctx->cfg.analytic_bytes;
+    const int lds_per_block = (entries + 1) * 256 * 4 + ctx->cfg.analytic_bytes;  // stack rows + the age row + analytic primitives
+    if (const char *e = getenv("RT_SPLIT_BUDGET")) ctx->cfg.split_budget = std::max(0, atoi(e));  // 0 = never split a shadow walk
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
     const size_t spill_entries = (size_t)std::max(0, ctx->bvh.max_stack - entries);
     if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;

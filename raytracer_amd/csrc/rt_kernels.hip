@@ -424,16 +424,41 @@ RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, RtRay &r, float &dist, u
     r.d = ld;
 }
 
-template <bool ANY, bool STATS, bool INDIRECT>
-RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries) {
+//
+// Long any-hit walks.  A launch cannot end before its longest ray, and a shadow ray can be very long: one that leaves a
+// point 10^7 units away (a horizon pixel on an infinite plane) carries a slab-test error bound many units wide and walks
+// through everything near its line (profiles/r01_configs.md: 712 724 steps for one ray, 0.57 s).  The subtrees on an
+// any-hit ray's stack are independent -- the ray is occluded iff ANY of them holds a hit -- so a lane whose ray has been
+// walking for more than `budget` wave iterations EXPORTS it: every stack entry (and cur / pend) becomes a work item
+// (ray index, subtree) in q.split, and the lane takes the next ray.  Up to RT_SPLIT_ROUNDS follow-up launches
+// (MODE 2) walk the items with all lanes, exporting again what is still long; the last one has no budget.  The ray's
+// join word (shC.w as u32) counts its outstanding items; an item that finds a hit sets RT_JOIN_OCCLUDED; the item
+// that brings the count to zero adds the pending radiance if the flag is clear.  Same sums, same bits as unsplit.
+#define RT_MODE_QUEUE 0   // the level's queue
+#define RT_MODE_RESID 1   // the rays the packet kernel handed over (q.resid holds their queue indices)
+#define RT_MODE_SPLIT 2   // work items of split any-hit walks (round `round` of the level)
+
+template <bool ANY, bool STATS, int MODE>
+RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries, int round,
+                       uint32_t budget) {
+    if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(level, round)] == 0) return;  // the usual case: nothing was split
     extern __shared__ uint32_t s_lds[];
     const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
-    const RtAnalytic an = stageAnalytic(sc, s_lds + stack_entries * RT_BLOCK);
+    // one LDS row behind the stack: the wave iteration at which the lane took its ray
+    RtLdsWord *const age = (RtLdsWord *)(s_lds + stack_entries * RT_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
+    const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);
     const int buf = level & 1;
-    // INDIRECT: the rays are those the packet kernel handed over (q.resid holds their queue indices)
-    const uint32_t n = INDIRECT ? q.counters[ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)]
+    constexpr bool INDIRECT = MODE == RT_MODE_RESID, SPLIT = MODE == RT_MODE_SPLIT;
+    static_assert(ANY || !SPLIT, "only any-hit walks are split");
+    const uint32_t n = SPLIT ? min(q.counters[RT_CNT_SPLIT(level, round)], q.split_cap)
+                     : INDIRECT ? q.counters[ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)]
                                 : (ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap));
-    uint32_t *work = q.counters + (ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
+    uint32_t *work = q.counters + (SPLIT ? RT_CNT_SPLIT(level, round) + 1 : ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
+    const uint2 *items_in = q.split[round & 1];
+    uint2 *items_out = q.split[(round + 1) & 1];          // the queue pass is round -1
+    uint32_t *items_out_count = q.counters + RT_CNT_SPLIT(level, round + 1);
+    uint32_t iter = 0;                                     // wave iterations of the walk loop so far (uniform)
+    bool occl = false;                                     // SPLIT: the finished item found a hit
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
     bool more = true;                      // wave-uniform: the queue may still hold unclaimed rays
@@ -454,14 +479,21 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     bool fin = false;
     uint32_t walk = 0;  // STATS: steps of the lane's current ray (the longest walk bounds a launch's tail)
     auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
-        if (ANY) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
+        bool add = true;
+        if (SPLIT) {  // the item that brings the ray's outstanding count to zero speaks for the ray
+            uint32_t *join = reinterpret_cast<uint32_t *>(q.shC + ri) + 3;
+            if (occl) atomicOr(join, RT_JOIN_OCCLUDED);
+            const uint32_t old = atomicSub(join, 1u);
+            add = !occl && old == 1u;  // (old carries the flag if any earlier item set it)
+            occl = false;
+        }
+        if (ANY && add) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
             atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
             atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
-        } else {
-            q.hits[ri] = make_float2(w.best_t, __uint_as_float(w.best_id));
         }
+        if (!ANY) q.hits[ri] = make_float2(w.best_t, __uint_as_float(w.best_id));
         fin = false;
     };
     // STATS build only: where a wave's time goes (shader clock): [0] refill cycles, [1] node-phase cycles, [2] node
@@ -470,13 +502,42 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tStart = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
-        const unsigned long long idle = __ballot(!has);
         const unsigned long long tRefill = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (ANY && budget) {  // uniform
+            const bool longLane = has && iter - age[laneNow()] > budget;
+            if (__ballot(longLane)) {
+                const uint32_t lane = laneId();
+                const uint32_t k = longLane ? (w.cur != RT_NODE_DONE ? 1u : 0u) + (w.pend != RT_NODE_DONE ? 1u : 0u) + (uint32_t)w.sp : 0u;
+                uint32_t incl = k;  // inclusive scan over the wave (rare path)
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d);
+                    if (lane >= (uint32_t)d) incl += t;
+                }
+                const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t base = waveReserve(items_out_count, total);
+                if (base + total <= q.split_cap) {
+                    if (longLane) {
+                        uint2 *out = items_out + base + (incl - k);
+                        if (w.cur != RT_NODE_DONE) *out++ = make_uint2(ray_i, w.cur);
+                        if (w.pend != RT_NODE_DONE) *out++ = make_uint2(ray_i, w.pend);
+                        while (w.sp) *out++ = make_uint2(ray_i, rtPop(stk, w.sp));
+                        // a ray of the queue pass had no join count yet; an item was itself one outstanding unit
+                        atomicAdd(reinterpret_cast<uint32_t *>(q.shC + ray_i) + 3, SPLIT ? k - 1u : k);
+                        w.cur = w.pend = RT_NODE_DONE;
+                        has = false;
+                    }
+                } else {  // no room: the rays walk on; the reserved slots inside the buffer must not hold garbage
+                    for (uint32_t sl = base + lane; sl < min(base + total, q.split_cap); sl += 64) items_out[sl] = make_uint2(RT_SPLIT_NULL, RT_NODE_DONE);
+                    if (longLane) age[laneNow()] = iter;  // try again a budget later
+                }
+            }
+        }
         if (STATS && !has && walk) {
             atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
             walk = 0;
         }
-        if (idle && more) {
+        const unsigned long long idle2 = __ballot(!has);
+        if (idle2 && more) {
             if (pool_next >= pool_end) {
                 uint32_t base = 0;
                 if (laneId() == 0) base = atomicAdd(work, RT_FETCH_BATCH);
@@ -484,20 +545,30 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 pool_next = min(base, n);
                 pool_end = min(base + RT_FETCH_BATCH, n);
             }
-            const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(idle);
-            const uint32_t rank = maskRankBelow(idle);
+            const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(idle2);
+            const uint32_t rank = maskRankBelow(idle2);
             // loads first (the new ray's record and, for a finished shadow ray, its pending colour): one round trip
             const bool take = !has && rank < avail;
             const uint32_t old_i = ray_i, old_sample = sample;
             float4 A = make_float4(0, 0, 0, 0), B = A, C = A;
+            uint32_t item_ref = RT_NODE_DONE;
+            bool nothing = false;  // the slot holds no ray
             if (take) {
-                ray_i = INDIRECT ? q.resid[pool_next + rank] : pool_next + rank;
-                A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
+                if (SPLIT) {
+                    const uint2 it = items_in[pool_next + rank];
+                    ray_i = it.x;
+                    item_ref = it.y;
+                    nothing = ray_i == RT_SPLIT_NULL;
+                } else {
+                    ray_i = INDIRECT ? q.resid[pool_next + rank] : pool_next + rank;
+                }
+                if (!nothing) A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
                 if (!ANY) B = q.rayB[buf][ray_i];
+                if (ANY && !SPLIT) nothing = __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
             }
             if (ANY && fin) C = q.shC[old_i];
             if (fin) writeResult(old_i, old_sample, C);
-            if (take && !(ANY && __float_as_uint(A.w) == RT_SHADOW_HOLE)) {  // (holes: unused slots of k_shade's slabs)
+            if (take && !nothing) {
                 float ldist = 0.0f;
                 if (ANY) {
                     rtShadowRay(sc, A, w.r, ldist, sample);
@@ -508,7 +579,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
                 rtInitWalk(sc, w, root_ref);
                 has = true;
-                if (ANY) {
+                if (ANY) age[laneNow()] = iter;
+                if (SPLIT) {
+                    w.best_t = ldist;
+                    w.cur = item_ref;  // the subtree (or leaf) this item stands for; the analytic primitives were tested in the queue pass
+                } else if (ANY) {
                     w.best_t = ldist;  // light distance
                     if (analyticOccluded(sc, an, w, ldist)) has = false;  // occluded: nothing to add
                 } else if (sample & RT_FLAG_INVALID) {  // slot of a pixel outside the image: recorded as a miss
@@ -550,7 +625,13 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
             } else if (nTri > 0) {
                 if (STATS && atTri) walk++;
-                if (atTri && rtTriStep<ANY, STATS>(sc, w, st)) has = false;  // occluded: the pending radiance is dropped
+                if (atTri && rtTriStep<ANY, STATS>(sc, w, st)) {  // occluded: the pending radiance is dropped
+                    has = false;
+                    if (SPLIT) {  // ... by the ray's last item (writeResult)
+                        fin = true;
+                        occl = true;
+                    }
+                }
                 if (STATS) {
                     prof[4] += __builtin_amdgcn_s_memtime() - tPhase;
                     prof[5]++;
@@ -561,7 +642,10 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 fin = true;
                 has = false;
             }
-        } while ((int)__popcll(__ballot(has)) >= leave_below);
+            ++iter;
+            // (every 1024 iterations the wave passes the top of the outer loop even if no lane is done: long lanes are
+            // looked for there)
+        } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & 1023u) != 0);
     }
     if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0));
     if (STATS) {
@@ -789,13 +873,14 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t 
     }
 }
 
-template <bool STATS, bool INDIRECT>
+template <bool STATS, int MODE>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<false, STATS, INDIRECT>(sc, root_ref, q, level, stack_entries);
+    traceQueue<false, STATS, MODE>(sc, root_ref, q, level, stack_entries, -1, 0u);
 }
-template <bool STATS, bool INDIRECT>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<true, STATS, INDIRECT>(sc, root_ref, q, level, stack_entries);
+template <bool STATS, int MODE>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries, int round,
+                                                     uint32_t budget) {
+    traceQueue<true, STATS, MODE>(sc, root_ref, q, level, stack_entries, round, budget);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1240,20 +1325,32 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 // packets first (when the tree allows a wave-level stack), then the per-lane kernel over what they handed back
 template <bool ANY>
 static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
-    const size_t lds = (size_t)cfg.stack_entries * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
+    const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
-#define RT_LAUNCH(K, S, I) hipLaunchKernelGGL((K<S, I>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
+    const uint32_t budget = ANY && q.split_cap ? (uint32_t)cfg.split_budget : 0u;
+#define RT_LAUNCHC(S, M) hipLaunchKernelGGL((k_closest<S, M>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
+#define RT_LAUNCHA(S, M, G, R, B) hipLaunchKernelGGL((k_any<S, M>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B)
 #define RT_LAUNCHP(A, S) hipLaunchKernelGGL((k_packet<A, S>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, level)
     if (cfg.packets && level < (ANY ? cfg.packet_levels_any : cfg.packet_levels_closest)) {
         if (ANY) { if (stats) RT_LAUNCHP(true, true); else RT_LAUNCHP(true, false); }
         else { if (stats) RT_LAUNCHP(false, true); else RT_LAUNCHP(false, false); }
-        if (ANY) { if (stats) RT_LAUNCH(k_any, true, true); else RT_LAUNCH(k_any, false, true); }
-        else { if (stats) RT_LAUNCH(k_closest, true, true); else RT_LAUNCH(k_closest, false, true); }
+        if (ANY) { if (stats) RT_LAUNCHA(true, RT_MODE_RESID, grid, -1, budget); else RT_LAUNCHA(false, RT_MODE_RESID, grid, -1, budget); }
+        else { if (stats) RT_LAUNCHC(true, RT_MODE_RESID); else RT_LAUNCHC(false, RT_MODE_RESID); }
     } else {
-        if (ANY) { if (stats) RT_LAUNCH(k_any, true, false); else RT_LAUNCH(k_any, false, false); }
-        else { if (stats) RT_LAUNCH(k_closest, true, false); else RT_LAUNCH(k_closest, false, false); }
+        if (ANY) { if (stats) RT_LAUNCHA(true, RT_MODE_QUEUE, grid, -1, budget); else RT_LAUNCHA(false, RT_MODE_QUEUE, grid, -1, budget); }
+        else { if (stats) RT_LAUNCHC(true, RT_MODE_QUEUE); else RT_LAUNCHC(false, RT_MODE_QUEUE); }
     }
-#undef RT_LAUNCH
+    if (ANY && budget) {
+        // follow-up rounds over the work items of split walks (almost always none: their waves read a zero count and
+        // leave); a quarter of the grid is plenty, the last round walks whatever is left to the end
+        const dim3 sgrid(gridFor(cfg, cfg.trace_blocks_per_cu >= 4 ? cfg.trace_blocks_per_cu / 4 : 1));
+        for (int r = 0; r < RT_SPLIT_ROUNDS; r++) {
+            const uint32_t b = r == RT_SPLIT_ROUNDS - 1 ? 0u : budget;
+            if (stats) RT_LAUNCHA(true, RT_MODE_SPLIT, sgrid, r, b); else RT_LAUNCHA(false, RT_MODE_SPLIT, sgrid, r, b);
+        }
+    }
+#undef RT_LAUNCHC
+#undef RT_LAUNCHA
 #undef RT_LAUNCHP
 }
 void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {

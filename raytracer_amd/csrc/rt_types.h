@@ -161,7 +161,8 @@ struct RtQueues {
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
     uint32_t *resid;           // rays the packet kernels hand to the per-lane kernels (queue indices)
-    uint32_t ray_cap, shadow_cap;
+    uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
+    uint32_t ray_cap, shadow_cap, split_cap;
 };
 
 // Device counters.  Every hot counter owns a 128-byte line: returning atomics on one line serialise at the memory
@@ -187,5 +188,11 @@ struct RtQueues {
 #define RT_CNT_RESID_ANY(d) ((92 + (d)) * RT_CNT_STRIDE)     // same for shadow rays
 #define RT_CNT_PWORK_CLOSEST(d) ((108 + (d)) * RT_CNT_STRIDE) // next unclaimed packet batch of level d (packet kernels)
 #define RT_CNT_PWORK_ANY(d) ((124 + (d)) * RT_CNT_STRIDE)
-#define RT_CNT_WORDS (140 * RT_CNT_STRIDE)
+// split rounds of the shadow kernels (rt_kernels.hip, "long any-hit walks"): per level and round the number of work
+// items queued for it (+0) and the next unclaimed one (+1)
+#define RT_SPLIT_ROUNDS 6
+#define RT_CNT_SPLIT(level, round) (140 * RT_CNT_STRIDE + ((level) * (RT_SPLIT_ROUNDS + 1) + (round)) * 2)
+#define RT_CNT_WORDS (140 * RT_CNT_STRIDE + 16 * (RT_SPLIT_ROUNDS + 1) * 2)
+#define RT_SPLIT_NULL 0xFFFFFFFFu     // ray index of an item that holds no work (reserved slots of a wave that could not export)
+#define RT_JOIN_OCCLUDED 0x80000000u  // join word of a split shadow ray (shC.w as u32): outstanding items | this flag
 

@@ -1,0 +1,34 @@
+"""Long any-hit walks are split into work items (rt_kernels.hip, "Long any-hit walks").  With the default budget no
+ray of the shipped scenes is ever split; a budget of ONE wave iteration splits nearly every shadow ray that is still
+walking at a refill, through every follow-up round.  The image must not change by a bit (the accumulators are fixed
+point, a ray's radiance is added exactly once by its last item or not at all)."""
+import numpy as np
+import pytest
+
+from conftest import get_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("competition", 128, 96, 4), ("sample", 160, 105, 16), ("stress:9", 96, 64, 4)])
+def test_split_walks_change_nothing(monkeypatch, name, w, h, spp):
+    from raytracer_amd.renderer import Renderer
+    scene = get_scene(name, False)
+
+    def render(budget):
+        monkeypatch.setenv("RT_SPLIT_BUDGET", str(budget))  # read at rt_commit
+        r = Renderer(0).set_scene(scene)
+        try:
+            return r.render(w, h, spp=spp, collect_stats=1)
+        finally:
+            r.close()
+
+    plain, split = render(0), render(1)
+    assert np.array_equal(plain["rgb8"], split["rgb8"])
+    assert np.array_equal(plain["rgbf"].view(np.uint32), split["rgbf"].view(np.uint32))
+    a, b = plain["stats"], split["stats"]
+    assert a["rays_shadow"] == b["rays_shadow"] and a["rays_closest"] == b["rays_closest"] and b["queue_overflow"] == 0
+    # splitting really happened: the longest single walk got (much) shorter, the work (nodes visited) did not shrink
+    print(f"{name}: longest shadow walk {a['max_walk_any']} -> {b['max_walk_any']}, shadow node visits {a['nodes_visited_any']} -> {b['nodes_visited_any']}")
+    assert b["max_walk_any"] < a["max_walk_any"]
+    assert b["nodes_visited_any"] >= a["nodes_visited_any"]
