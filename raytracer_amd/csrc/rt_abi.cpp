@@ -661,7 +661,11 @@ int rt_commit(rt_context *ctx) {
     if (const char *e = getenv("RT_ANY_ORDERED")) ctx->dev.any_ordered = atoi(e) != 0;
     ctx->cfg.analytic_bytes = (int)(units.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
     const int lds_per_block = (entries + 1) * 256 * 4 + ctx->cfg.analytic_bytes;  // stack rows + the age row + analytic primitives
-    if (const char *e = getenv("RT_SPLIT_BUDGET")) ctx->cfg.split_budget = std::max(0, atoi(e));  // 0 = never split a shadow walk
+    if (const char *e = getenv("RT_SPLIT_BUDGET")) {  // 0 = never split a shadow walk; rounded down to a power of two
+        int b = std::max(0, atoi(e)), p2 = 0;
+        while (b > 1) { b >>= 1; p2++; }
+        ctx->cfg.split_budget = atoi(e) > 0 ? 1 << p2 : 0;
+    }
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
     const size_t spill_entries = (size_t)std::max(0, ctx->bvh.max_stack - entries);
     if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;

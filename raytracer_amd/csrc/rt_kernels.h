@@ -13,7 +13,7 @@ struct RtLaunchCfg {
     int packet_levels_closest = 1;
     int packet_levels_any = 0;
     int analytic_bytes = 0;        // LDS behind the stack holding the staged spheres + planes
-    int split_budget = 4096;       // wave iterations after which a shadow ray's walk is split into work items (0 = never)
+    int split_budget = 1024;       // wave iterations (a power of two) after which a shadow ray's walk is split into work items (0 = never)
     int trace_blocks_per_cu = 4;   // resident 256-thread blocks per CU for the traversal kernels (LDS-limited)
 };
 

@@ -458,6 +458,8 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     uint2 *items_out = q.split[(round + 1) & 1];          // the queue pass is round -1
     uint32_t *items_out_count = q.counters + RT_CNT_SPLIT(level, round + 1);
     uint32_t iter = 0;                                     // wave iterations of the walk loop so far (uniform)
+    // the wave passes the top of its outer loop (where long lanes are looked for) at least every period + 1 iterations
+    const uint32_t period = (SPLIT && budget && budget < 1024u) ? budget - 1u : 1023u;  // budget is a power of two
     bool occl = false;                                     // SPLIT: the finished item found a hit
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
@@ -643,9 +645,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 has = false;
             }
             ++iter;
-            // (every 1024 iterations the wave passes the top of the outer loop even if no lane is done: long lanes are
-            // looked for there)
-        } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & 1023u) != 0);
+        } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & period) != 0);
     }
     if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0));
     if (STATS) {
@@ -1345,7 +1345,8 @@ static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t r
         // leave); a quarter of the grid is plenty, the last round walks whatever is left to the end
         const dim3 sgrid(gridFor(cfg, cfg.trace_blocks_per_cu >= 4 ? cfg.trace_blocks_per_cu / 4 : 1));
         for (int r = 0; r < RT_SPLIT_ROUNDS; r++) {
-            const uint32_t b = r == RT_SPLIT_ROUNDS - 1 ? 0u : budget;
+            // items get an eighth of the budget: a round then lasts ~0.15 ms and the items multiply faster
+            const uint32_t b = r == RT_SPLIT_ROUNDS - 1 ? 0u : (budget >= 64u ? budget / 8u : budget);
             if (stats) RT_LAUNCHA(true, RT_MODE_SPLIT, sgrid, r, b); else RT_LAUNCHA(false, RT_MODE_SPLIT, sgrid, r, b);
         }
     }
