@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="primary samples per wavefront chunk (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two instrumented passes")
-    ap.add_argument("--cpu-sample", default="160x120")
+    ap.add_argument("--cpu-sample", default="480x360")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gather even with one rank (rehearses the RCCL path on a 1-GPU box)")
     a = ap.parse_args()
