@@ -14,7 +14,10 @@ def collect(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+            full = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = full.split("<")[0]
+            if k == "k_any" and full.rstrip().endswith(", 2>"):
+                k = "k_any_split"  # follow-up rounds over the items of split walks (usually empty)
             tot[k] += float(r["Counter_Value"])
             calls[k] += 1
     return tot, calls
