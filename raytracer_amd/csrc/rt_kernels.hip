@@ -403,13 +403,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Traversal kernels: persistent lanes with dynamic ray fetch.  A wave reserves RT_FETCH_BATCH consecutive queue
+// Traversal kernels: persistent lanes with dynamic ray fetch.  A wave reserves RT_FETCH_BATCH_* consecutive queue
 // entries at a time (one returning atomic per batch); a lane whose ray has terminated takes the next entry of the
 // wave's batch instead of idling until the slowest ray of its wave is done.  The walk leaves its loop to refill as
 // soon as fewer than RT_REFILL_BELOW lanes hold a ray.  Ray order does not affect results: hit records go to the
 // ray's own slot and radiance is accumulated in fixed point.
-#define RT_FETCH_BATCH 256u
-#define RT_REFILL_BELOW 24
+// Batch sizes (overridable for parameter sweeps, scripts/build_variants.sh; measured on the 4K/64 spp bench): the
+// work counter is ONE address, and at 256 shadow rays per atomic its returning atomics saturate (k_any 332 ms; 512:
+// 298 ms; 1024: 300 ms); closest-hit queues hold fewer, longer walks and prefer the better balance of 256 (234 ms;
+// 1024: 247 ms).  Refill threshold: 16 lanes is 4 ms better than 24 or 32.
+#ifndef RT_FETCH_BATCH_ANY
+#define RT_FETCH_BATCH_ANY 512u
+#endif
+#ifndef RT_FETCH_BATCH_CLOSEST
+#define RT_FETCH_BATCH_CLOSEST 256u
+#endif
+#ifndef RT_REFILL_BELOW
+#define RT_REFILL_BELOW 16
+#endif
 
 // Shadow-queue record -> the Ray of is_shadowed() (main.cpp:49): the record holds the shaded point and the light's
 // index; direction, light distance and the epsilon-offset origin are recomputed with the expressions k_shade uses
@@ -449,11 +460,19 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);
     const int buf = level & 1;
     constexpr bool INDIRECT = MODE == RT_MODE_RESID, SPLIT = MODE == RT_MODE_SPLIT;
+    constexpr uint32_t batch = ANY ? RT_FETCH_BATCH_ANY : RT_FETCH_BATCH_CLOSEST;
     static_assert(ANY || !SPLIT, "only any-hit walks are split");
     const uint32_t n = SPLIT ? min(q.counters[RT_CNT_SPLIT(level, round)], q.split_cap)
                      : INDIRECT ? q.counters[ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)]
                                 : (ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap));
     uint32_t *work = q.counters + (SPLIT ? RT_CNT_SPLIT(level, round) + 1 : ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
+    // The level's queue is cut into RT_WORK_PARTS contiguous parts with a cursor each (on its own 128-byte line): one
+    // cursor for the whole chip saturates -- a returning atomic on one address retires every ~10 ns.  A wave starts
+    // in the part of its XCD (workgroups go round-robin over the 8 XCDs) and moves on when a part is used up.
+    constexpr uint32_t PARTS = MODE == RT_MODE_QUEUE ? RT_WORK_PARTS : 1u;
+    uint32_t *work_parts = q.counters + (ANY ? RT_CNT_WORKP_ANY(level, 0) : RT_CNT_WORKP_CLOSEST(level, 0));
+    const uint32_t part_len = PARTS > 1 ? ((n + PARTS - 1) / PARTS + batch - 1) / batch * batch : n;
+    uint32_t part = PARTS > 1 ? blockIdx.x % PARTS : 0u, parts_done = 0;  // wave-uniform
     const uint2 *items_in = q.split[round & 1];
     uint2 *items_out = q.split[(round + 1) & 1];          // the queue pass is round -1
     uint32_t *items_out_count = q.counters + RT_CNT_SPLIT(level, round + 1);
@@ -540,13 +559,20 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
         }
         const unsigned long long idle2 = __ballot(!has);
         if (idle2 && more) {
-            if (pool_next >= pool_end) {
+            while (pool_next >= pool_end && parts_done < PARTS) {
                 uint32_t base = 0;
-                if (laneId() == 0) base = atomicAdd(work, RT_FETCH_BATCH);
+                if (laneId() == 0) base = atomicAdd(PARTS > 1 ? work_parts + part * RT_CNT_STRIDE : work, batch);
                 base = __builtin_amdgcn_readfirstlane(base);
-                pool_next = min(base, n);
-                pool_end = min(base + RT_FETCH_BATCH, n);
+                const uint32_t lo = part * part_len, hi = min(lo + part_len, n);
+                if (lo + base < hi && lo < n) {
+                    pool_next = lo + base;
+                    pool_end = min(pool_next + batch, hi);
+                } else {  // this part is used up: on to the next
+                    part = part + 1 == PARTS ? 0u : part + 1;
+                    parts_done++;
+                }
             }
+            if (parts_done >= PARTS) more = false;
             const uint32_t avail = pool_end - pool_next, want = (uint32_t)__popcll(idle2);
             const uint32_t rank = maskRankBelow(idle2);
             // loads first (the new ray's record and, for a finished shadow ray, its pending colour): one round trip
@@ -597,7 +623,6 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
             }
             pool_next += min(want, avail);
-            if (pool_next >= pool_end && pool_end >= n) more = false;
             if (STATS) {
                 prof[0] += __builtin_amdgcn_s_memtime() - tRefill;
                 prof[8]++;
@@ -888,7 +913,7 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t roo
 // `level`; remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
 template <bool PROF>
-__global__ __launch_bounds__(RT_BLOCK, 4) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles, uint32_t slab) {
     // Output slots come from WAVE-PRIVATE slabs: a wave reserves `slab` consecutive slots of the shadow queue per light
     // (and of the next level's ray queue) with one atomic and fills them over its next iterations -- no barrier, no

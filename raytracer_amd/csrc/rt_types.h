@@ -10,7 +10,9 @@
 #define RT_MAX_LIGHTS 16         // the light index shares a word with the 28-bit sample index in the shadow queue
 #define RT_MAX_SPHERES 64
 #define RT_MAX_PLANES 64
+#ifndef RT_LDS_STACK
 #define RT_LDS_STACK 16          // traversal stack rows per lane kept in LDS; deeper entries (rare) spill to global memory
+#endif
 #define RT_EPSILON 0.001f       // reference main.cpp:21
 #define RT_ACC_SCALE 4294967296.0   // fixed-point accumulators: 2^32 steps per unit of radiance
 #define RT_ACC_LIMIT 16777216.0f    // contributions are clamped to +-2^24 before conversion
@@ -142,9 +144,15 @@ struct RtFrameDev {
 #define RT_SAMPLE_MASK 0x0FFFFFFFu
 #define RT_FLAG_HAS_REFR_SIBLING 0x10000000u  // reflection ray whose refraction sibling sits in the next slot
 #define RT_SHADOW_HOLE 0xFFFFFFFFu            // w of a shadow record that holds no ray (unused slot of a k_shade slab)
+#ifndef RT_SLAB_MAX
 #define RT_SLAB_MAX 1024u                    // slots a k_shade wave reserves at a time, per light / for the next level
+#endif
+#ifndef RT_SHADE_BLOCKS_PER_CU
 #define RT_SHADE_BLOCKS_PER_CU 4
+#endif
+#ifndef RT_SHADE_SEGMENT
 #define RT_SHADE_SEGMENT 1024u                // consecutive queue entries a k_shade wave shades before it jumps
+#endif
 #define RT_BLOCK 256                         // threads per block of every kernel
 #define RT_FLAG_INVALID 0x20000000u           // slot of a pixel outside the image or unused slab slot: traced as a miss, never shaded
 
@@ -188,11 +196,16 @@ struct RtQueues {
 #define RT_CNT_RESID_ANY(d) ((92 + (d)) * RT_CNT_STRIDE)     // same for shadow rays
 #define RT_CNT_PWORK_CLOSEST(d) ((108 + (d)) * RT_CNT_STRIDE) // next unclaimed packet batch of level d (packet kernels)
 #define RT_CNT_PWORK_ANY(d) ((124 + (d)) * RT_CNT_STRIDE)
+// cursors of the parts a level's queue is cut into for the dynamic fetch (one 128-byte line each)
+#define RT_WORK_PARTS 8
+#define RT_CNT_WORKP_CLOSEST(d, p) (RT_CNT_WORKP_BASE + ((d) * RT_WORK_PARTS + (p)) * RT_CNT_STRIDE)
+#define RT_CNT_WORKP_ANY(d, p) (RT_CNT_WORKP_BASE + ((16 + (d)) * RT_WORK_PARTS + (p)) * RT_CNT_STRIDE)
 // split rounds of the shadow kernels (rt_kernels.hip, "long any-hit walks"): per level and round the number of work
 // items queued for it (+0) and the next unclaimed one (+1)
 #define RT_SPLIT_ROUNDS 6
 #define RT_CNT_SPLIT(level, round) (140 * RT_CNT_STRIDE + ((level) * (RT_SPLIT_ROUNDS + 1) + (round)) * 2)
-#define RT_CNT_WORDS (140 * RT_CNT_STRIDE + 16 * (RT_SPLIT_ROUNDS + 1) * 2)
+#define RT_CNT_WORKP_BASE ((140 + 8) * RT_CNT_STRIDE)  // (16 levels x 7 rounds x 2 words of RT_CNT_SPLIT fit 7 strides)
+#define RT_CNT_WORDS (RT_CNT_WORKP_BASE + 32 * RT_WORK_PARTS * RT_CNT_STRIDE)
 #define RT_SPLIT_NULL 0xFFFFFFFFu     // ray index of an item that holds no work (reserved slots of a wave that could not export)
 #define RT_JOIN_OCCLUDED 0x80000000u  // join word of a split shadow ray (shC.w as u32): outstanding items | this flag
 

@@ -1,0 +1,14 @@
+# bench.py (no CPU leg) on every library variant in build_variants/ (on the GPU box: the tree is a scratch copy)
+mkdir -p gpurun_out/variants
+cp raytracer_amd/csrc/libraytracer_hip.so /tmp/base.so
+for so in /tmp/base.so build_variants/*.so; do
+  name=$(basename $so .so)
+  cp $so raytracer_amd/csrc/libraytracer_hip.so
+  timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/variants/$name.json 2> gpurun_out/variants/$name.err || { echo $name failed; tail -3 gpurun_out/variants/$name.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/variants/$name.json"))
+print("$name", round(d["ms_per_step"],1), "ms", {k:round(v,1) for k,v in d["kernel_ms"].items() if k in ("ms_closest","ms_shade","ms_any")}, flush=True)
+PY
+done
+cp /tmp/base.so raytracer_amd/csrc/libraytracer_hip.so
