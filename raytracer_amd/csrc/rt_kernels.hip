@@ -693,7 +693,9 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
 // entered when ANY lane's box test passes, so results are those of the per-lane walk (boxes only cull; the exact
 // triangle test decides).  Packets whose directions do not share one octant, or that exceed a step budget
 // (incoherent rays: the union of their walks is large), are handed to the per-lane kernels through q.resid.
-#define RT_PACKET_BATCH 4u       // packets a wave reserves per atomic
+#ifndef RT_PACKET_BATCH
+#define RT_PACKET_BATCH 8u       // packets a wave reserves per atomic (2: +18 ms, the cursor saturates; 4, 8, 16 equal)
+#endif
 #define RT_PACKET_BUDGET 160     // node steps after which a packet is declared incoherent
 
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
