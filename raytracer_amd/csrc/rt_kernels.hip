@@ -696,7 +696,9 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
 #ifndef RT_PACKET_BATCH
 #define RT_PACKET_BATCH 8u       // packets a wave reserves per atomic (2: +18 ms, the cursor saturates; 4, 8, 16 equal)
 #endif
+#ifndef RT_PACKET_BUDGET
 #define RT_PACKET_BUDGET 160     // node steps after which a packet is declared incoherent
+#endif
 
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) u16v *RtScalarRecs;  // constant address space: uniform loads become s_load

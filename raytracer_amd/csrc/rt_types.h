@@ -197,7 +197,9 @@ struct RtQueues {
 #define RT_CNT_PWORK_CLOSEST(d) ((108 + (d)) * RT_CNT_STRIDE) // next unclaimed packet batch of level d (packet kernels)
 #define RT_CNT_PWORK_ANY(d) ((124 + (d)) * RT_CNT_STRIDE)
 // cursors of the parts a level's queue is cut into for the dynamic fetch (one 128-byte line each)
+#ifndef RT_WORK_PARTS
 #define RT_WORK_PARTS 8
+#endif
 #define RT_CNT_WORKP_CLOSEST(d, p) (RT_CNT_WORKP_BASE + ((d) * RT_WORK_PARTS + (p)) * RT_CNT_STRIDE)
 #define RT_CNT_WORKP_ANY(d, p) (RT_CNT_WORKP_BASE + ((16 + (d)) * RT_WORK_PARTS + (p)) * RT_CNT_STRIDE)
 // split rounds of the shadow kernels (rt_kernels.hip, "long any-hit walks"): per level and round the number of work
