@@ -642,7 +642,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             const bool atNode = has && !(w.cur & RT_NODE_LEAF), atTri = has && w.pend != RT_NODE_DONE;
             const int nNode = (int)__popcll(__ballot(atNode)), nTri = (int)__popcll(__ballot(atTri));
             const unsigned long long tPhase = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-            if (nNode >= nTri && nNode > 0) {
+#ifndef RT_VOTE_NODE_NUM  // node phase iff nNode * NUM >= nTri * DEN (sweep variants; 1/1 = the larger group)
+#define RT_VOTE_NODE_NUM 1
+#define RT_VOTE_NODE_DEN 1
+#endif
+            if (nNode * RT_VOTE_NODE_NUM >= nTri * RT_VOTE_NODE_DEN && nNode > 0) {
                 if (atNode) rtNodeStep<ANY, STATS>(sc, w, stk, st);
                 if (STATS && atNode) walk++;
                 if (STATS) {
