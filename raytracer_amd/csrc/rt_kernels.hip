@@ -947,9 +947,45 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     // [4] next-level emission, [5] iterations
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
 #define RT_PROF_MARK(k) if (PROF) { tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tp; tp = tn; }
-    for (uint64_t seg0 = (uint64_t)gwave * seg; seg0 < n; seg0 += (uint64_t)nwaves * seg)
-    for (uint32_t i = (uint32_t)seg0 + lane, segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n); i - lane < segEnd; i += 64) {
-        bool active = i < segEnd;
+    // Only HITS are shaded, and a third of the traced rays of a frame miss: the wave first SCANS its segment (64 hit
+    // records at a time: 8 bytes each), appends the indices of the hits to a ring in LDS, and shades 64 of them at a
+    // time with every lane busy.  At level 0 the scan also stores the zero that initialises the accumulator of a
+    // sample whose ray missed (see below).  Order is kept, so sibling pairs and runs of equal samples stay neighbours.
+    __shared__ uint32_t s_ring[RT_BLOCK / 64][128];
+    uint32_t *const ring = s_ring[threadIdx.x >> 6];
+    uint64_t seg0 = (uint64_t)gwave * seg;           // wave-uniform scan state
+    bool moreSeg = seg0 < n;
+    uint32_t scan = (uint32_t)seg0, segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n), head = 0, count = 0;
+    while (moreSeg || count) {
+        while (count < 64 && moreSeg) {
+            const uint32_t j = scan + lane;
+            const bool valid = j < segEnd;
+            const bool hit = valid && __float_as_uint(q.hits[valid ? j : 0].y) != RT_ID_MISS;
+            if (level == 0 && valid && !hit) {  // miss, or slot outside the image: the sample's first and only level-0 entry
+                long long *acc = q.accum + 3ull * (__float_as_uint(q.rayB[buf][j].w) & RT_SAMPLE_MASK);
+                acc[0] = 0;
+                acc[1] = 0;
+                acc[2] = 0;
+            }
+            const unsigned long long hm = __ballot(hit);
+            if (hit) ring[(head + count + maskRankBelow(hm)) & 127u] = j;
+            count += (uint32_t)__popcll(hm);
+            scan += 64;
+            if (scan >= segEnd) {  // next segment of this wave
+                seg0 += (uint64_t)nwaves * seg;
+                moreSeg = seg0 < n;
+                scan = (uint32_t)seg0;
+                segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t takeN = min(count, 64u);
+        bool active = lane < takeN;
+        const uint32_t i = active ? ring[(head + lane) & 127u] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        head = (head + takeN) & 127u;
+        count -= takeN;
         float2 hrec = make_float2(0.0f, __uint_as_float(RT_ID_MISS));
         float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_INVALID));
         if (active) {
@@ -959,20 +995,17 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         }
         const uint32_t id = __float_as_uint(hrec.y);
         const uint32_t sflags = __float_as_uint(B.w), sample = sflags & RT_SAMPLE_MASK;
-        if (active && level == 0 && primid_tiles && !(sflags & RT_FLAG_INVALID) && (sample % (uint32_t)spp) == 0) {
-            // primitive hit by sample 0 of the pixel, written tile-major at y*16+x
+        if (active && level == 0 && primid_tiles && (sample % (uint32_t)spp) == 0) {
+            // primitive hit by sample 0 of the pixel, written tile-major at y*16+x (misses keep the buffer's RT_PRIM_MISS)
             const uint32_t pm = sample / (uint32_t)spp, m = pm & 255u;
             const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
-            uint32_t prim = RT_PRIM_MISS;
-            if (id != RT_ID_MISS) {
-                const uint32_t kind = id & RT_ID_KIND_MASK;
-                if (kind == RT_ID_SPHERE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.spheres[id & 0xFFFF].object;
-                else if (kind == RT_ID_PLANE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.planes[id & 0xFFFF].object;
-                else prim = sc.tri_shade[id].prim;
-            }
+            const uint32_t kind = id & RT_ID_KIND_MASK;
+            uint32_t prim;
+            if (kind == RT_ID_SPHERE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.spheres[id & 0xFFFF].object;
+            else if (kind == RT_ID_PLANE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.planes[id & 0xFFFF].object;
+            else prim = sc.tri_shade[id].prim;
             primid_tiles[(size_t)(tile0 + (pm >> 8)) * RT_TILE_PIXELS + py * RT_TILE + px] = prim;
         }
-        active = active && id != RT_ID_MISS;
 
         // per-lane state carried from the shading step to the (block-uniform) emission steps
         V3 P = v3s(0), ns = v3s(0), view = v3s(0), normal = v3s(0), dcol = v3s(0), mspec = v3s(0), hT = v3s(0), hB = v3s(0);
@@ -1051,9 +1084,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         }
 
         if (level > 0) accumulateRuns(q.accum, active, sample, amb0);  // ambient term of the hit (levels >= 1)
-        if (level == 0 && i < segEnd) {
+        if (level == 0 && active) {
             // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
             // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.
+            // (misses: the scan above)
             long long *acc = q.accum + 3ull * sample;
             acc[0] = rtToFixed(amb0.x);
             acc[1] = rtToFixed(amb0.y);
