@@ -10,8 +10,10 @@
 //   k_hitinfo / k_eval_texture / k_eval_perlin   test hooks of the C ABI
 //
 // Queues are compacted with 64-wide ballots (mbcnt gives the lane offset inside the wave); k_shade's waves reserve
-// their output slots in slabs (one atomic per RT_SLAB_MAX slots), the unused remainder of a slab is flagged as holes.
-// Traversal keeps a per-lane stack in LDS, laid out [entry][lane] so that a wave's push/pop is conflict-free.
+// their output slots in slabs (one atomic per RT_SLAB_MAX slots), the unused remainder of a slab is flagged as holes,
+// and they shade hits only (compacted through an LDS ring).  The traversal kernels are persistent: lanes fetch rays
+// dynamically (8 cursors per queue), keep a per-lane stack in LDS laid out [entry][lane] (conflict-free push/pop),
+// and export shadow rays whose walks get long as work items for follow-up rounds ("Long any-hit walks").
 #include <hip/hip_runtime.h>
 #include "rt_device.h"
 #include "rt_kernels.h"
