@@ -616,7 +616,7 @@ int rt_commit(rt_context *ctx) {
         s.object = ctx->tri_object[t];
         s.prim = (uint32_t)t;
         s.rank = rank[t];
-        s._pad = 0;
+        s.material = ctx->object_material[(size_t)ctx->tri_object[t]];
     }
     if (ctx->d_records.upload(records) || ctx->d_shade.upload(shade) || ctx->d_nodes_p.upload(ctx->bvh.nodes_p)) return 1;
     if (ctx->d_spheres.upload(units) || ctx->d_planes.upload(ctx->planes)) return 1;

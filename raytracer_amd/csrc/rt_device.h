@@ -389,7 +389,7 @@ RT_DEV void rtReconstructHit(const RtSceneDev &sc, const RtRay &r, float t, uint
             h.uv = alpha * V2{s.tA[0], s.tA[1]} + beta * V2{s.tB[0], s.tB[1]} + gamma * V2{s.tC[0], s.tC[1]};
         }
         h.object = s.object;
-        h.material = sc.object_material[s.object];
+        h.material = s.material;
         h.prim = s.prim;
         h.triangle = (int32_t)id;
     }

@@ -74,7 +74,7 @@ struct RtTriShade {
     int32_t object;   // scene object index
     uint32_t prim;    // global triangle index (scene order) -- the primitive id reported to the caller
     uint32_t rank;    // position in the reference's candidate order: resolves exact distance ties like MeshLoader.h:399-404
-    uint32_t _pad;
+    int32_t material; // = object_material[object] (saves k_shade a dependent load)
 };
 
 struct RtSphere {       // a transformed unit primitive: Sphere (Objects.h:12-104) or Cone (Objects.h:188-278); 240 bytes
