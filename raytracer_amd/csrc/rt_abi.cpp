@@ -147,7 +147,8 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     if (ctx->d_accum.alloc(samples * 3)) return 1;
     if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
     if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
-    const size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
+    size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
+    if (const char *e = getenv("RT_SPLIT_CAP")) split_cap = (size_t)std::max(64, atoi(e));  // (test knob: forces the no-room path)
     if (ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) return 1;
     ctx->ws_samples = samples;
     ctx->ws_fanout = fo;

@@ -32,3 +32,23 @@ def test_split_walks_change_nothing(monkeypatch, name, w, h, spp):
     print(f"{name}: longest shadow walk {a['max_walk_any']} -> {b['max_walk_any']}, shadow node visits {a['nodes_visited_any']} -> {b['nodes_visited_any']}")
     assert b["max_walk_any"] < a["max_walk_any"]
     assert b["nodes_visited_any"] >= a["nodes_visited_any"]
+
+
+def test_split_queue_without_room_changes_nothing(monkeypatch):
+    """the item queue of a round is finite: a wave that finds no room keeps walking its long rays and fills the slots it
+    had reserved inside the buffer with null items"""
+    from raytracer_amd.renderer import Renderer
+    scene = get_scene("competition", False)
+
+    def render(budget, cap):
+        monkeypatch.setenv("RT_SPLIT_BUDGET", str(budget))
+        monkeypatch.setenv("RT_SPLIT_CAP", str(cap))
+        r = Renderer(0).set_scene(scene)
+        try:
+            return r.render(128, 96, spp=4)
+        finally:
+            r.close()
+
+    plain, tight = render(0, 1 << 22), render(1, 200)
+    assert np.array_equal(plain["rgbf"].view(np.uint32), tight["rgbf"].view(np.uint32))
+    assert plain["stats"]["rays_shadow"] == tight["stats"]["rays_shadow"] and tight["stats"]["queue_overflow"] == 0
