@@ -922,6 +922,32 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t roo
 // PhongModel without its nested closest()/is_shadowed() calls (main.cpp:81-213).  One lane per traced ray of
 // `level`; remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
+// Colour-only math of PhongModel (its results feed radiance, never a ray): the reference's libm calls are not bit-exact
+// on the device anyway (BASELINE tolerance: 8-bit RGB within 1, PSNR >= 50 dB), so these use the hardware's
+// transcendental units instead of ocml's full-accuracy sequences.  Geometry (directions, distances, hit tests) keeps
+// IEEE division and square root.
+#ifndef RT_LIBM_COLOR_MATH  // (define it to get ocml's powf / cosf(acosf) / the double division back: +18 ms per frame, same 8-bit images)
+// std::pow(x, y) as main.cpp:142 uses it, followed by max(0, .): negative bases give NaN (-> 0) unless y is an integer
+RT_DEV float colorPowMax0(float x, float y) {
+    if (y == 0.0f) return 1.0f;
+    const float ax = fabsf(x);
+    float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(ax));  // v_exp_f32(y * v_log_f32(|x|))
+    if (x < 0.0f) {
+        const float fy = floorf(y);
+        const bool isInt = fy == y, odd = isInt && (fy * 0.5f != floorf(fy * 0.5f));
+        if (!isInt || odd) r = 0.0f;  // NaN or a negative value: max(0, .) is 0
+    }
+    return r == r ? r : 0.0f;
+}
+#define RT_COLOR_POW_MAX0(x, y) colorPowMax0((x), (y))
+#define RT_COLOR_ATTENUATION(d) __builtin_amdgcn_rcpf((d) * (d))
+#define RT_COS_OF_ANGLE(a, b) gclamp(dot((a), (b)), -1.0f, 1.0f)
+#else
+#define RT_COLOR_POW_MAX0(x, y) smax(0.0f, powf((x), (y)))
+#define RT_COLOR_ATTENUATION(d) ((float)(1.0 / ((double)(d) * (double)(d))))
+#define RT_COS_OF_ANGLE(a, b) cosf(rtAngle((a), (b)))
+#endif
+
 template <bool PROF>
 __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles, uint32_t slab) {
@@ -1073,8 +1099,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 const float n1 = entering ? 1.0f : m.sigma, n2 = entering ? m.sigma : 1.0f;
                 const float eta = n1 / n2;
                 if (rtRefract(-view, entering ? ns : -ns, eta, refrDir)) {
-                    const float O1 = cosf(rtAngle(ns, view));
-                    const float O2 = cosf(rtAngle(-ns, refrDir));
+                    const float O1 = RT_COS_OF_ANGLE(ns, view);
+                    const float O2 = RT_COS_OF_ANGLE(-ns, refrDir);
                     const double ra = (double)((n1 * O1 - n2 * O2) / (n1 * O1 + n2 * O2));
                     const double rb = (double)((n1 * O2 - n2 * O1) / (n1 * O2 + n2 * O1));
                     fresnelR = (float)(0.5 * (ra * ra + rb * rb));
@@ -1128,7 +1154,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 const float diffuse = smax(0.0f, dot(ld, ns));       // :104
                 const V3 hv = normalize(ld + view);                  // :106
                 const float distance = smax(0.1f, dl);               // :109
-                const float attenuation = (float)(1.0 / ((double)distance * (double)distance));  // :110 (double pow)
+                const float attenuation = RT_COLOR_ATTENUATION(distance);  // :110 (double pow)
                 const V3 diffusion = attenuation * lc * dcol * diffuse;
                 V3 spec = v3s(0.0f);
                 if (aniso) {  // main.cpp:123-139
@@ -1141,7 +1167,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                         spec = (mspec * NdotL * expf(exponent)) / (sqrtf(NdotL * NdotV) * 4 * pi * alpha_x * alpha_y);
                     }
                 } else {  // :141-142; std::max(0.0f, NaN) == 0.0f
-                    const float specular = smax(0.0f, powf(dot(hv, ns), 4 * shiny));
+                    const float specular = RT_COLOR_POW_MAX0(dot(hv, ns), 4 * shiny);
                     spec = attenuation * lc * mspec * specular;
                 }
                 V3 c3 = diffusion + spec;
