@@ -93,6 +93,16 @@ RT_DEV uint32_t rtPop(const RtStack &s, int &sp) {  // requires sp > 0
     --sp;
     return sp < s.lds_entries ? s.lds[sp * RT_BLOCK + laneNow()] : s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride + laneNow()];
 }
+// the same with the lane's column handed in (a node step pushes up to three times: one mbcnt pair for all of them)
+RT_DEV void rtPushL(const RtStack &s, int &sp, uint32_t v, uint32_t ln) {
+    if (sp < s.lds_entries) s.lds[sp * RT_BLOCK + ln] = v;
+    else s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride + ln] = v;
+    sp++;
+}
+RT_DEV uint32_t rtPopL(const RtStack &s, int &sp, uint32_t ln) {  // requires sp > 0
+    --sp;
+    return sp < s.lds_entries ? s.lds[sp * RT_BLOCK + ln] : s.spill[(size_t)(sp - s.lds_entries) * s.spill_stride + ln];
+}
 RT_DEV RtStack rtMakeStack(uint32_t *lds_base, uint32_t *spill, int lds_entries) {
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);  // first thread of this wave
     RtStack s;
@@ -184,6 +194,7 @@ RT_DEV bool rtTriStep(const RtSceneDev &sc, RtWalk &w, RtTraversalStats &st) {
 template <bool ANY, bool STATS>
 RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTraversalStats &st) {
     RT_LOAD_RECORD(w.cur)
+    const uint32_t ln = laneNow();  // the lane's stack column, once for every push / pop of this step
     if (STATS) st.nodes++;
     const V3 m = v3(q0.w * w.inv.x, q3.z * w.inv.y, q3.w * w.inv.z);  // scale / d (scale is a power of two: exact)
     const float ax = __builtin_fmaf(q0.x, w.inv.x, -w.oi.x), ay = __builtin_fmaf(q0.y, w.inv.y, -w.oi.y),
@@ -215,10 +226,10 @@ RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTr
 #pragma unroll
         for (int c = 3; c >= 0; c--)
             if (key[c] != 0xFFFFFFFFu) {
-                if (next != RT_NODE_DONE) rtPush(stk, w.sp, next);
+                if (next != RT_NODE_DONE) rtPushL(stk, w.sp, next, ln);
                 next = ref[c];
             }
-        w.cur = next != RT_NODE_DONE ? next : (w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE);
+        w.cur = next != RT_NODE_DONE ? next : (w.sp ? rtPopL(stk, w.sp, ln) : RT_NODE_DONE);
         return;
     }
     // sort (entry distance, reference) pairs: 5 comparators
@@ -232,11 +243,11 @@ RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTr
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
     if (key[0] == 0xFFFFFFFFu) {
-        w.cur = w.sp ? rtPop(stk, w.sp) : RT_NODE_DONE;
+        w.cur = w.sp ? rtPopL(stk, w.sp, ln) : RT_NODE_DONE;
     } else {  // descend into the nearest child, push the others far-first
-        if (key[3] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[3]);
-        if (key[2] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[2]);
-        if (key[1] != 0xFFFFFFFFu) rtPush(stk, w.sp, ref[1]);
+        if (key[3] != 0xFFFFFFFFu) rtPushL(stk, w.sp, ref[3], ln);
+        if (key[2] != 0xFFFFFFFFu) rtPushL(stk, w.sp, ref[2], ln);
+        if (key[1] != 0xFFFFFFFFu) rtPushL(stk, w.sp, ref[1], ln);
         w.cur = ref[0];
     }
 }
