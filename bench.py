@@ -174,6 +174,17 @@ def main():
         result["roofline_valu"] = {"kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
                                    "note": "80 flop per 4-wide node (4 slab tests) + 80 per triangle test (SURVEY.md 8(d))"}
+        vpath = os.path.join(REPO, "profiles", "r01_pmc_valu.json")
+        if os.path.exists(vpath):  # committed rocprofv3 --pmc SQ_INSTS_VALU pass of this workload + the opcode micro-benchmark
+            v = json.load(open(vpath)).get("kernels", {}).get(name)
+            if v and v.get("SQ_INSTS_VALU"):
+                per_ray = v["SQ_INSTS_VALU"] / max(nrays, 1)
+                result["roofline_valu"]["issue"] = {
+                    "valu_wave_insts_per_ray": per_ray,
+                    "simd_cycles_per_valu_inst": (ms / 1e3) * 2.4e9 * 1024 / (per_ray * nrays),
+                    "note": "instruction count per ray from profiles/r01_pmc_valu.json x this run's time, 1024 SIMDs at 2.4 GHz; "
+                            "the node step's opcode mix costs ~3.7 cycles per instruction (profiles/r01_valu_issue.md): the kernel "
+                            "issues at the SIMDs' limit"}
         result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
     if rank == 0 and not a.no_cpu and world == 1:
         try:
