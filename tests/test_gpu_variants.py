@@ -48,9 +48,15 @@ def test_sixteen_lights():
     check(s, 131, 77, label="16 lights")
 
 
-@pytest.mark.parametrize("depth", [4, 5])
+@pytest.mark.parametrize("depth", [4, 5, 15])
 def test_deeper_bounces(depth):
     check(get_scene("sample", False), 97, 61, depth=depth, label=f"depth {depth}")
+
+
+def test_depth_eight_on_the_refractive_scene():
+    """bounce depth 8 on the competition scene (ice, crystal and water refract and reflect at once): the levels past
+    the queue fan-out cap of 16 rays per sample still fit, because capacity is per chunk, not per sample"""
+    check(get_scene("competition", False), 64, 48, depth=8, label="competition depth 8")
 
 
 def test_analytic_primitives_only():
