@@ -88,8 +88,9 @@ typedef struct rt_render_params {
     int32_t tile_rank;      /* this context renders tiles t with t % tile_world == tile_rank (16x16 tiles, main.cpp:565) */
     int32_t tile_world;     /* 1 = whole image */
     int64_t chunk_samples;  /* primary samples per wavefront chunk; 0 = default */
-    int32_t collect_stats;  /* bit0: count BVH node fetches / triangle tests in-kernel (slower);
-                               bit1: time every kernel class with HIP events on the launch stream (ms_gen ...) */
+    int32_t collect_stats;  /* bit0: count BVH node fetches / triangle tests and the longest walk in-kernel;
+                               bit1: time every kernel class with HIP events on the launch stream (ms_gen ...);
+                               bit2: wave-time profile of the kernels (prof_closest / prof_any / prof_shade; much slower) */
     int32_t _pad;
 } rt_render_params;
 
@@ -109,7 +110,7 @@ typedef struct rt_stats {
     uint64_t nodes_visited_any; /* BVH nodes fetched by shadow rays (collect_stats & 1 only) */
     uint64_t tris_tested_any;   /* triangle tests of shadow rays    (collect_stats & 1 only) */
     uint64_t bvh_max_stack;     /* traversal stack entries a ray can need in this BVH */
-    /* collect_stats & 1 only: wave-time breakdown of the traversal kernels in shader clocks, summed over waves:
+    /* collect_stats & 4 only: wave-time breakdown of the traversal kernels in shader clocks, summed over waves:
      * [0] refill (fetch + ray set-up + result writes), [1] node phases, [2] their count, [3] lanes active in them,
      * [4] triangle phases, [5] count, [6] lanes, [7] wave lifetime, [8] refills, [9] rays fetched */
     uint64_t prof_closest[10];

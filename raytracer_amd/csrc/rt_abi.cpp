@@ -234,7 +234,7 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
 void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
-               bool stats, KernelTimer &kt, rt_stats *st, uint64_t level0_rays, bool level0_traced = false) {
+               int stats, KernelTimer &kt, rt_stats *st, uint64_t level0_rays, bool level0_traced = false) {
     for (int level = 0; level <= max_depth; level++) {
         if (!(level == 0 && level0_traced)) {  // each level's queue is claimed once (dynamic fetch counters)
             kt.begin(1);
@@ -242,7 +242,7 @@ void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, 
             kt.end();
         }
         kt.begin(2);
-        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles, stats, level0_rays << level);
+        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles, stats >= 2, level0_rays << level);
         kt.end();
         kt.begin(3);
         rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
@@ -313,7 +313,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
 
     RtLaunchCfg cfg = ctx->cfg;
     cfg.stream = stream;
-    const bool stats_on = (p->collect_stats & 1) != 0;
+    const int stats_on = (p->collect_stats & 4) ? 2 : (p->collect_stats & 1) ? 1 : 0;  // counters / + wave-time profile
     KernelTimer kt;
     kt.on = (p->collect_stats & 2) != 0;
     kt.stream = stream;
@@ -754,9 +754,9 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
         if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
         rtLaunchRaysFromHost(cfg, d_rays.p, m, ctx->q);
         // level 0 closest hit first: the hit records of the batch are reported from it
-        rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, false);
+        rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, 0);
         if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
-        runLevels(ctx, cfg, depth, 1, 0, nullptr, false, kt, st, m, true);
+        runLevels(ctx, cfg, depth, 1, 0, nullptr, 0, kt, st, m, true);
         rtLaunchBatchColors(cfg, ctx->q, m, d_col.p);
         std::vector<uint32_t> hc(RT_CNT_WORDS);
         e = hipStreamSynchronize(cfg.stream);

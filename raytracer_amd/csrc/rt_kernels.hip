@@ -462,10 +462,11 @@ RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, RtRay &r, float &dist, u
 #define RT_MODE_RESID 1   // the rays the packet kernel handed over (q.resid holds their queue indices)
 #define RT_MODE_SPLIT 2   // work items of split any-hit walks (round `round` of the level)
 
-template <bool ANY, bool STATS, int MODE>
+template <bool ANY, int STATS, int MODE>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries, int round,
                        uint32_t budget) {
     if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(level, round)] == 0) return;  // the usual case: nothing was split
+    constexpr bool COUNT = STATS >= 1, PROF = STATS >= 2;
     extern __shared__ uint32_t s_lds[];
     const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
     // one LDS row behind the stack: the wave iteration at which the lane took its ray
@@ -534,9 +535,9 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // phases, [3] lanes active in them, [4] triangle-phase cycles, [5] triangle phases, [6] lanes, [7] wave lifetime,
     // [8] refills, [9] rays fetched
     unsigned long long prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long tStart = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long tStart = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
-        const unsigned long long tRefill = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long tRefill = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
         if (ANY && budget) {  // uniform
             const bool longLane = has && iter - age[laneNow()] > budget;
             if (__ballot(longLane)) {
@@ -566,7 +567,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
             }
         }
-        if (STATS && !has && walk) {
+        if (COUNT && !has && walk) {
             atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
             walk = 0;
         }
@@ -636,7 +637,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
             }
             pool_next += min(want, avail);
-            if (STATS) {
+            if (PROF) {
                 prof[0] += __builtin_amdgcn_s_memtime() - tRefill;
                 prof[8]++;
                 prof[9] += min(want, avail);
@@ -654,29 +655,29 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             if (has) rtPostponeLeaf(w, stk);
             const bool atNode = has && !(w.cur & RT_NODE_LEAF), atTri = has && w.pend != RT_NODE_DONE;
             const int nNode = (int)__popcll(__ballot(atNode)), nTri = (int)__popcll(__ballot(atTri));
-            const unsigned long long tPhase = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+            const unsigned long long tPhase = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
 #ifndef RT_VOTE_NODE_NUM  // node phase iff nNode * NUM >= nTri * DEN (sweep variants; 1/1 = the larger group)
 #define RT_VOTE_NODE_NUM 1
 #define RT_VOTE_NODE_DEN 1
 #endif
             if (nNode * RT_VOTE_NODE_NUM >= nTri * RT_VOTE_NODE_DEN && nNode > 0) {
-                if (atNode) rtNodeStep<ANY, STATS>(sc, w, stk, st);
-                if (STATS && atNode) walk++;
-                if (STATS) {
+                if (atNode) rtNodeStep<ANY, COUNT>(sc, w, stk, st);
+                if (COUNT && atNode) walk++;
+                if (PROF) {
                     prof[1] += __builtin_amdgcn_s_memtime() - tPhase;
                     prof[2]++;
                     prof[3] += nNode;
                 }
             } else if (nTri > 0) {
-                if (STATS && atTri) walk++;
-                if (atTri && rtTriStep<ANY, STATS>(sc, w, st)) {  // occluded: the pending radiance is dropped
+                if (COUNT && atTri) walk++;
+                if (atTri && rtTriStep<ANY, COUNT>(sc, w, st)) {  // occluded: the pending radiance is dropped
                     has = false;
                     if (SPLIT) {  // ... by the ray's last item (writeResult)
                         fin = true;
                         occl = true;
                     }
                 }
-                if (STATS) {
+                if (PROF) {
                     prof[4] += __builtin_amdgcn_s_memtime() - tPhase;
                     prof[5]++;
                     prof[6] += nTri;
@@ -690,9 +691,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
         } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & period) != 0);
     }
     if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0));
-    if (STATS) {
+    if (COUNT) {
         if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
+    }
+    if (PROF) {
         prof[7] = __builtin_amdgcn_s_memtime() - tStart;
         if (laneId() == 0) {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + (ANY ? RT_CNT_PROF_ANY : RT_CNT_PROF_CLOSEST));
@@ -919,11 +922,11 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t 
     }
 }
 
-template <bool STATS, int MODE>
+template <int STATS, int MODE>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
     traceQueue<false, STATS, MODE>(sc, root_ref, q, level, stack_entries, -1, 0u);
 }
-template <bool STATS, int MODE>
+template <int STATS, int MODE>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries, int round,
                                                      uint32_t budget) {
     traceQueue<true, STATS, MODE>(sc, root_ref, q, level, stack_entries, round, budget);
@@ -1430,21 +1433,25 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 }
 // packets first (when the tree allows a wave-level stack), then the per-lane kernel over what they handed back
 template <bool ANY>
-static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
+static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats) {
     const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
     const uint32_t budget = ANY && q.split_cap ? (uint32_t)cfg.split_budget : 0u;
 #define RT_LAUNCHC(S, M) hipLaunchKernelGGL((k_closest<S, M>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
 #define RT_LAUNCHA(S, M, G, R, B) hipLaunchKernelGGL((k_any<S, M>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B)
 #define RT_LAUNCHP(A, S) hipLaunchKernelGGL((k_packet<A, S>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, level)
+// (stats: 0 = plain, 1 = counters, 2 = counters + wave-time profile)
+#define RT_BY_STATS(CALL) do { if (stats >= 2) { CALL(2); } else if (stats == 1) { CALL(1); } else { CALL(0); } } while (0)
+#define RT_PK(S) RT_LAUNCHP(ANY, (S) != 0)
+#define RT_A_RESID(S) RT_LAUNCHA(S, RT_MODE_RESID, grid, -1, budget)
+#define RT_A_QUEUE(S) RT_LAUNCHA(S, RT_MODE_QUEUE, grid, -1, budget)
+#define RT_C_RESID(S) RT_LAUNCHC(S, RT_MODE_RESID)
+#define RT_C_QUEUE(S) RT_LAUNCHC(S, RT_MODE_QUEUE)
     if (cfg.packets && level < (ANY ? cfg.packet_levels_any : cfg.packet_levels_closest)) {
-        if (ANY) { if (stats) RT_LAUNCHP(true, true); else RT_LAUNCHP(true, false); }
-        else { if (stats) RT_LAUNCHP(false, true); else RT_LAUNCHP(false, false); }
-        if (ANY) { if (stats) RT_LAUNCHA(true, RT_MODE_RESID, grid, -1, budget); else RT_LAUNCHA(false, RT_MODE_RESID, grid, -1, budget); }
-        else { if (stats) RT_LAUNCHC(true, RT_MODE_RESID); else RT_LAUNCHC(false, RT_MODE_RESID); }
+        RT_BY_STATS(RT_PK);
+        if (ANY) RT_BY_STATS(RT_A_RESID); else RT_BY_STATS(RT_C_RESID);
     } else {
-        if (ANY) { if (stats) RT_LAUNCHA(true, RT_MODE_QUEUE, grid, -1, budget); else RT_LAUNCHA(false, RT_MODE_QUEUE, grid, -1, budget); }
-        else { if (stats) RT_LAUNCHC(true, RT_MODE_QUEUE); else RT_LAUNCHC(false, RT_MODE_QUEUE); }
+        if (ANY) RT_BY_STATS(RT_A_QUEUE); else RT_BY_STATS(RT_C_QUEUE);
     }
     if (ANY && budget) {
         // follow-up rounds over the work items of split walks (almost always none: their waves read a zero count and
@@ -1453,17 +1460,25 @@ static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t r
         for (int r = 0; r < RT_SPLIT_ROUNDS; r++) {
             // items get an eighth of the budget: a round then lasts ~0.15 ms and the items multiply faster
             const uint32_t b = r == RT_SPLIT_ROUNDS - 1 ? 0u : (budget >= 64u ? budget / 8u : budget);
-            if (stats) RT_LAUNCHA(true, RT_MODE_SPLIT, sgrid, r, b); else RT_LAUNCHA(false, RT_MODE_SPLIT, sgrid, r, b);
+#define RT_A_SPLIT(S) RT_LAUNCHA(S, RT_MODE_SPLIT, sgrid, r, b)
+            RT_BY_STATS(RT_A_SPLIT);
+#undef RT_A_SPLIT
         }
     }
+#undef RT_BY_STATS
+#undef RT_PK
+#undef RT_A_RESID
+#undef RT_A_QUEUE
+#undef RT_C_RESID
+#undef RT_C_QUEUE
 #undef RT_LAUNCHC
 #undef RT_LAUNCHA
 #undef RT_LAUNCHP
 }
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats) {
     launchTrace<false>(cfg, sc, root_ref, q, level, stats);
 }
-void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, bool stats) {
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats) {
     launchTrace<true>(cfg, sc, root_ref, q, level, stats);
 }
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,

@@ -7,7 +7,7 @@ W, H, SPP = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1920, 108
 scene = sys.argv[4] if len(sys.argv) > 4 else "competition"
 r = Renderer(0).set_scene(FlatScene.builtin(scene))
 r.render(W, H, spp=SPP, want=())
-st = r.render(W, H, spp=SPP, collect_stats=1, want=())["stats"]
+st = r.render(W, H, spp=SPP, collect_stats=5, want=())["stats"]
 print("max_stack", st["bvh_max_stack"], "depth", st["bvh_depth"], "nodes", st["bvh_nodes"])
 for name, rays in (("prof_closest", st["rays_closest"]), ("prof_any", st["rays_shadow"])):
     p = st[name]
