@@ -174,6 +174,12 @@ def main():
         result["roofline_valu"] = {"kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
                                    "note": "80 flop per 4-wide node (4 slab tests) + 80 per triangle test (SURVEY.md 8(d))"}
+        pr = counted["prof_any" if name == "k_any" else "prof_closest"]  # counted in-kernel (cheap statistics build)
+        if pr[2] and pr[5] and pr[8]:
+            result["roofline_valu"]["lanes"] = {
+                "lanes_per_node_phase": pr[3] / pr[2], "lanes_per_triangle_phase": pr[6] / pr[5],
+                "node_phases": pr[2], "triangle_phases": pr[5], "rays_per_refill": pr[9] / pr[8],
+                "note": "of 64 lanes; a phase issues its instructions for the whole wave"}
         vpath = os.path.join(REPO, "profiles", "r01_pmc_valu.json")
         if os.path.exists(vpath):  # committed rocprofv3 --pmc SQ_INSTS_VALU pass of this workload + the opcode micro-benchmark
             v = json.load(open(vpath)).get("kernels", {}).get(name)

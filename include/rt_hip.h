@@ -110,7 +110,8 @@ typedef struct rt_stats {
     uint64_t nodes_visited_any; /* BVH nodes fetched by shadow rays (collect_stats & 1 only) */
     uint64_t tris_tested_any;   /* triangle tests of shadow rays    (collect_stats & 1 only) */
     uint64_t bvh_max_stack;     /* traversal stack entries a ray can need in this BVH */
-    /* collect_stats & 4 only: wave-time breakdown of the traversal kernels in shader clocks, summed over waves:
+    /* wave-time breakdown of the traversal kernels, summed over waves; the counts ([2] [3] [5] [6] [8] [9]) come with
+     * collect_stats & 1, the shader clocks ([0] [1] [4] [7]) with collect_stats & 4:
      * [0] refill (fetch + ray set-up + result writes), [1] node phases, [2] their count, [3] lanes active in them,
      * [4] triangle phases, [5] count, [6] lanes, [7] wave lifetime, [8] refills, [9] rays fetched */
     uint64_t prof_closest[10];

@@ -637,8 +637,8 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
             }
             pool_next += min(want, avail);
-            if (PROF) {
-                prof[0] += __builtin_amdgcn_s_memtime() - tRefill;
+            if (PROF) prof[0] += __builtin_amdgcn_s_memtime() - tRefill;
+            if (COUNT) {  // (uniform counters: scalar adds)
                 prof[8]++;
                 prof[9] += min(want, avail);
             }
@@ -663,8 +663,8 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             if (nNode * RT_VOTE_NODE_NUM >= nTri * RT_VOTE_NODE_DEN && nNode > 0) {
                 if (atNode) rtNodeStep<ANY, COUNT>(sc, w, stk, st);
                 if (COUNT && atNode) walk++;
-                if (PROF) {
-                    prof[1] += __builtin_amdgcn_s_memtime() - tPhase;
+                if (PROF) prof[1] += __builtin_amdgcn_s_memtime() - tPhase;
+                if (COUNT) {
                     prof[2]++;
                     prof[3] += nNode;
                 }
@@ -677,8 +677,8 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                         occl = true;
                     }
                 }
-                if (PROF) {
-                    prof[4] += __builtin_amdgcn_s_memtime() - tPhase;
+                if (PROF) prof[4] += __builtin_amdgcn_s_memtime() - tPhase;
+                if (COUNT) {
                     prof[5]++;
                     prof[6] += nTri;
                 }
@@ -694,12 +694,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     if (COUNT) {
         if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
-    }
-    if (PROF) {
-        prof[7] = __builtin_amdgcn_s_memtime() - tStart;
-        if (laneId() == 0) {
+        if (PROF) prof[7] = __builtin_amdgcn_s_memtime() - tStart;
+        if (laneId() == 0) {  // counts of phases / lanes / refills / rays with COUNT, their clocks with PROF
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + (ANY ? RT_CNT_PROF_ANY : RT_CNT_PROF_CLOSEST));
-            for (int k = 0; k < 10; k++) atomicAdd(dst + k, prof[k]);
+            for (int k = 0; k < 10; k++)
+                if (prof[k]) atomicAdd(dst + k, prof[k]);
         }
     }
 }
