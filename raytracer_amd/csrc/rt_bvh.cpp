@@ -73,15 +73,22 @@ void parallelRange(size_t lo, size_t hi, int threads, F fn) {
 
 double nowSeconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// What the builder knows of a triangle.  The records themselves are partitioned (not an index array into side arrays):
+// every pass over a node is then a sequential stream instead of a gather per triangle, which is what bounds the build
+// of a multi-million-triangle scene.
+struct Prim {
+    Box box;
+    float c[3];    // centroid of the box
+    uint32_t idx;  // triangle number in the caller's order
+};
+
 struct BuildTask { uint32_t self, lo, hi; int depth; };
 
 // One builder = one node array.  The scene-level builder walks the top of the tree (its big nodes bin in parallel)
 // and, below `cutoff` triangles, defers subtrees as tasks; worker threads build those into private node arrays that
-// are appended afterwards (disjoint ranges of `index`, so the partitioning needs no locks).
+// are appended afterwards (disjoint ranges of `prims`, so the partitioning needs no locks).
 struct Builder {
-    const Box *triBox = nullptr;
-    const float *centroid = nullptr;  // 3 per triangle
-    uint32_t *index = nullptr;        // permutation being partitioned
+    Prim *prims = nullptr;            // the permutation being partitioned, as whole records
     std::vector<RtNode> nodes;
     int maxDepth = 0;
     uint32_t cutoff = 0;              // 0: build everything here
@@ -97,7 +104,7 @@ struct Builder {
         }
     }
 
-    // builds the subtree of triangles index[lo, hi) into node `self`
+    // builds the subtree of triangles prims[lo, hi) into node `self`
     void build(uint32_t self, uint32_t lo, uint32_t hi, int depth) {
         const uint32_t count = hi - lo;
         if (cutoff && count <= cutoff) {
@@ -105,15 +112,15 @@ struct Builder {
             return;
         }
         maxDepth = std::max(maxDepth, depth);
-        const int nt = count >= (1u << 20) ? threads : 1;  // only the few huge nodes at the top are worth threads
+        const int nt = count >= (1u << 17) ? threads : 1;  // only the few huge nodes at the top are worth threads
         Box box, cbox;
         {
             std::vector<Box> pb(nt), pc(nt);
             parallelRange(lo, hi, nt, [&](int t, size_t a, size_t e) {
                 Box b1, c1;
                 for (size_t i = a; i < e; i++) {
-                    b1.grow(triBox[index[i]]);
-                    c1.grow(&centroid[3 * (size_t)index[i]]);
+                    b1.grow(prims[i].box);
+                    c1.grow(prims[i].c);
                 }
                 pb[t] = b1;
                 pc[t] = c1;
@@ -130,35 +137,44 @@ struct Builder {
         };
         if (count <= 1) return makeLeaf();
 
-        // binned SAH over the three axes
+        // binned SAH over the three axes, binned in one pass over the records
         float bestCost = INFINITY;
         int bestAxis = -1, bestSplit = -1;
+        struct Bins { Box box[3][kBins]; uint32_t cnt[3][kBins]; };
+        float cmin3[3], scale3[3];
         for (int axis = 0; axis < 3; axis++) {
-            const float cmin = cbox.mn[axis], cext = cbox.mx[axis] - cbox.mn[axis];
-            if (!(cext > 0)) continue;
-            Box bins[kBins];
-            uint32_t cnt[kBins] = {0};
-            const float scale = kBins / cext;
-            {
-                struct Part { Box bins[kBins]; uint32_t cnt[kBins]; };
-                std::vector<Part> part(nt);
-                parallelRange(lo, hi, nt, [&](int tid, size_t a, size_t e) {
-                    Part &p = part[tid];
-                    for (int b = 0; b < kBins; b++) p.cnt[b] = 0;
-                    for (size_t i = a; i < e; i++) {
-                        const uint32_t t = index[i];
-                        int b = (int)((centroid[3 * (size_t)t + axis] - cmin) * scale);
+            const float cext = cbox.mx[axis] - cbox.mn[axis];
+            cmin3[axis] = cbox.mn[axis];
+            scale3[axis] = cext > 0 ? kBins / cext : 0.0f;  // a flat axis lands in bin 0 and is skipped below
+        }
+        Bins all;
+        std::memset(all.cnt, 0, sizeof all.cnt);
+        {
+            std::vector<Bins> part(nt > 1 ? nt : 0);
+            parallelRange(lo, hi, nt, [&](int tid, size_t a, size_t e) {
+                Bins &p = nt > 1 ? part[tid] : all;
+                if (nt > 1) std::memset(p.cnt, 0, sizeof p.cnt);
+                for (size_t i = a; i < e; i++) {
+                    const Prim &pr = prims[i];
+                    for (int axis = 0; axis < 3; axis++) {
+                        int b = (int)((pr.c[axis] - cmin3[axis]) * scale3[axis]);
                         b = std::min(std::max(b, 0), kBins - 1);
-                        p.bins[b].grow(triBox[t]);
-                        p.cnt[b]++;
+                        p.box[axis][b].grow(pr.box);
+                        p.cnt[axis][b]++;
                     }
-                });
-                for (int tid = 0; tid < nt; tid++)
+                }
+            });
+            for (size_t tid = 0; tid < part.size(); tid++)
+                for (int axis = 0; axis < 3; axis++)
                     for (int b = 0; b < kBins; b++) {
-                        bins[b].grow(part[tid].bins[b]);
-                        cnt[b] += part[tid].cnt[b];
+                        all.box[axis][b].grow(part[tid].box[axis][b]);
+                        all.cnt[axis][b] += part[tid].cnt[axis][b];
                     }
-            }
+        }
+        for (int axis = 0; axis < 3; axis++) {
+            if (!(cbox.mx[axis] - cbox.mn[axis] > 0)) continue;
+            const Box *bins = all.box[axis];
+            const uint32_t *cnt = all.cnt[axis];
             float rightArea[kBins];
             uint32_t rightCnt[kBins];
             Box acc;
@@ -191,12 +207,12 @@ struct Builder {
         uint32_t mid;
         if (bestAxis >= 0) {
             const float cmin = cbox.mn[bestAxis], scale = kBins / (cbox.mx[bestAxis] - cbox.mn[bestAxis]);
-            auto it = std::partition(index + lo, index + hi, [&](uint32_t t) {
-                int b = (int)((centroid[3 * (size_t)t + bestAxis] - cmin) * scale);
+            auto it = std::partition(prims + lo, prims + hi, [&](const Prim &t) {
+                int b = (int)((t.c[bestAxis] - cmin) * scale);
                 b = std::min(std::max(b, 0), kBins - 1);
                 return b <= bestSplit;
             });
-            mid = (uint32_t)(it - index);
+            mid = (uint32_t)(it - prims);
         } else {
             mid = lo;  // all centroids coincide
         }
@@ -207,9 +223,8 @@ struct Builder {
         if (depth >= 40 && bestAxis >= 0) {
             const int axis = bestAxis;
             mid = lo + count / 2;
-            std::nth_element(index + lo, index + mid, index + hi, [&](uint32_t a, uint32_t b) {
-                return centroid[3 * (size_t)a + axis] < centroid[3 * (size_t)b + axis];
-            });
+            std::nth_element(prims + lo, prims + mid, prims + hi,
+                             [&](const Prim &a, const Prim &b) { return a.c[axis] < b.c[axis]; });
         }
         const uint32_t left = (uint32_t)nodes.size();
         nodes.emplace_back();
@@ -352,23 +367,19 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     const bool verbose = std::getenv("RT_VERBOSE") != nullptr;
     const double t0 = nowSeconds();
     const int threads = buildThreads();
-    std::vector<Box> triBox((size_t)n);
-    std::vector<float> centroid(3 * (size_t)n);
-    std::vector<uint32_t> index((size_t)n);
+    std::vector<Prim> prims((size_t)n);
     parallelRange(0, (size_t)n, threads, [&](int, size_t a, size_t e) {
         for (size_t t = a; t < e; t++) {
-            Box &bx = triBox[t];
-            bx.grow(v0 + 3 * t);
-            bx.grow(v1 + 3 * t);
-            bx.grow(v2 + 3 * t);
-            for (int k = 0; k < 3; k++) centroid[3 * t + k] = 0.5f * (bx.mn[k] + bx.mx[k]);
-            index[t] = (uint32_t)t;
+            Prim &pr = prims[t];
+            pr.box.grow(v0 + 3 * t);
+            pr.box.grow(v1 + 3 * t);
+            pr.box.grow(v2 + 3 * t);
+            for (int k = 0; k < 3; k++) pr.c[k] = 0.5f * (pr.box.mn[k] + pr.box.mx[k]);
+            pr.idx = (uint32_t)t;
         }
     });
     Builder b;
-    b.triBox = triBox.data();
-    b.centroid = centroid.data();
-    b.index = index.data();
+    b.prims = prims.data();
     b.threads = threads;
     b.cutoff = (threads > 1 && n >= (1 << 18)) ? (uint32_t)std::max<int64_t>(n / (16 * (int64_t)threads), 4096) : 0u;
     b.nodes.reserve(2 * (size_t)n + 2);
@@ -384,9 +395,7 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
             pool.emplace_back([&] {
                 for (size_t k; (k = next.fetch_add(1)) < b.tasks.size();) {
                     Builder &w = sub[k];
-                    w.triBox = b.triBox;
-                    w.centroid = b.centroid;
-                    w.index = b.index;
+                    w.prims = b.prims;
                     w.nodes.resize(1);
                     std::memset(w.nodes.data(), 0, sizeof(RtNode));
                     w.build(0, b.tasks[k].lo, b.tasks[k].hi, b.tasks[k].depth);
@@ -406,7 +415,11 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
         }
     }
     const double t2 = nowSeconds();
-    out.order = std::move(index);
+    out.order.resize((size_t)n);
+    parallelRange(0, (size_t)n, threads, [&](int, size_t a, size_t e) {
+        for (size_t i = a; i < e; i++) out.order[i] = prims[i].idx;
+    });
+    std::vector<Prim>().swap(prims);
     out.binary_nodes = (int64_t)b.nodes.size();
     const RtNode &root = b.nodes[1];
     if (root.b) {  // the whole scene is one leaf
