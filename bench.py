@@ -189,8 +189,8 @@ def main():
                     "valu_wave_insts_per_ray": per_ray,
                     "simd_cycles_per_valu_inst": (ms / 1e3) * 2.4e9 * 1024 / (per_ray * nrays),
                     "note": "instruction count per ray from profiles/r01_pmc_valu.json x this run's time, 1024 SIMDs at 2.4 GHz; "
-                            "the node step's opcode mix costs ~3.7 cycles per instruction (profiles/r01_valu_issue.md): the kernel "
-                            "issues at the SIMDs' limit"}
+                            "the node step's opcode mix costs ~3.7 cycles per instruction (profiles/r01_valu_issue.md): the "
+                            "closer this figure is to 3.7, the closer the kernel is to the SIMDs' issue limit"}
         result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
     if rank == 0 and not a.no_cpu and world == 1:
         try:

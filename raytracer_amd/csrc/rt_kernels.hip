@@ -676,7 +676,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
 #define RT_VOTE_NODE_NUM 1
 #define RT_VOTE_NODE_DEN 1
 #endif
-            if (nNode * RT_VOTE_NODE_NUM >= nTri * RT_VOTE_NODE_DEN && nNode > 0) {
+#ifndef RT_VOTE_ANY_NUM  // any-hit: a new ray's first triangle step is its cached occluder, so triangle phases get a head start
+#define RT_VOTE_ANY_NUM 2   // (k_any on the 4K frame: 1/1 260 ms, 2/3 255, 1/2 257, 1/3 260, 1/4 266)
+#define RT_VOTE_ANY_DEN 3
+#endif
+            if (nNode * (ANY ? RT_VOTE_ANY_NUM : RT_VOTE_NODE_NUM) >= nTri * (ANY ? RT_VOTE_ANY_DEN : RT_VOTE_NODE_DEN) && nNode > 0) {
                 if (atNode) rtNodeStep<ANY, COUNT>(sc, w, stk, st);
                 if (COUNT && atNode) walk++;
                 if (PROF) prof[1] += __builtin_amdgcn_s_memtime() - tPhase;
