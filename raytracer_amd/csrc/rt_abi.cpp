@@ -660,6 +660,8 @@ int rt_commit(rt_context *ctx) {
     }
     ctx->dev.any_ordered = 0;  // tuning knob: shadow rays descend near-first (costs ~1 % on the competition scene)
     if (const char *e = getenv("RT_ANY_ORDERED")) ctx->dev.any_ordered = atoi(e) != 0;
+    ctx->dev.occluder_cache = 1;  // RT_OCCLUDER_CACHE=0: shadow queries independent of scheduling down to the last float bit
+    if (const char *e = getenv("RT_OCCLUDER_CACHE")) ctx->dev.occluder_cache = atoi(e) != 0;
     ctx->cfg.analytic_bytes = (int)(units.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
     const int lds_per_block = (entries + 1) * 256 * 4 + ctx->cfg.analytic_bytes;  // stack rows + the age row + analytic primitives
     if (const char *e = getenv("RT_SPLIT_BUDGET")) {  // 0 = never split a shadow walk; rounded down to a power of two

@@ -517,7 +517,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // order of the tests is free.  Neighbouring shadow rays (a slab holds rays from neighbouring hits towards one light)
     // are mostly blocked by the same triangle: a new ray starts with the last occluder found in this wave as its
     // postponed leaf, i.e. it is tested in the ray's first triangle phase.  A hit ends the walk before it began; a miss
-    // costs one triangle step (4K frame: k_any 282 -> 259 ms).
+    // costs one triangle step (4K frame: k_any 282 -> 259 ms).  The cached test skips the box tests on the way to the
+    // triangle: where the reference's exact test accepts a triangle whose boxes the ray misses (grazing rays: the test
+    // does not check the distance to the plane), the answer depends on the cache, i.e. on scheduling.  Measured: no
+    // float bit of the 4K competition frame moves between runs; in the 4 M-triangle stress frame one pixel of 8.3 M
+    // does (8-bit images and counts identical).  RT_OCCLUDER_CACHE=0 (rt_commit) turns the cache off.
     uint32_t last_occ = RT_NODE_DONE;  // single-triangle leaf reference
     bool occ_new = false;              // found since the wave's last refill
     auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
@@ -643,7 +647,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 } else if (ANY) {
                     w.best_t = ldist;  // light distance
                     if (analyticOccluded(sc, an, w, ldist)) has = false;  // occluded: nothing to add
-                    w.pend = last_occ;
+                    if (sc.occluder_cache) w.pend = last_occ;
                 } else if (sample & RT_FLAG_INVALID) {  // slot of a pixel outside the image: recorded as a miss
                     w.best_t = INFINITY;
                     w.best_id = RT_ID_MISS;

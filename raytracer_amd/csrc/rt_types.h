@@ -120,6 +120,7 @@ struct RtSceneDev {
     float bound;                 // max |coordinate| of any node box (slab-test error bound, rt_kernels.hip)
     int32_t n_nodes, n_tris, n_spheres, n_planes, n_lights, n_objects, n_materials;
     int32_t any_ordered;         // shadow rays descend near-first like closest-hit rays (chosen at rt_commit)
+    int32_t occluder_cache;      // k_any starts a ray on the triangle that last occluded a ray of its wave (rt_commit)
 };
 
 // Camera + image constants of the tile loop, precomputed on the host exactly as main.cpp:561-563 does.

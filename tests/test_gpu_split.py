@@ -31,7 +31,34 @@ def test_split_walks_change_nothing(monkeypatch, name, w, h, spp):
     # splitting really happened: the longest single walk got (much) shorter, the work (nodes visited) did not shrink
     print(f"{name}: longest shadow walk {a['max_walk_any']} -> {b['max_walk_any']}, shadow node visits {a['nodes_visited_any']} -> {b['nodes_visited_any']}")
     assert b["max_walk_any"] < a["max_walk_any"]
-    assert b["nodes_visited_any"] >= a["nodes_visited_any"]
+    # (k_any's occluder cache makes the number of visits depend a little on scheduling: 2 % slack)
+    assert b["nodes_visited_any"] >= 0.98 * a["nodes_visited_any"]
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("competition", 256, 192, 16), ("sample", 160, 105, 16), ("stress:9", 192, 128, 4)])
+def test_occluder_cache_changes_no_image(monkeypatch, name, w, h, spp):
+    """k_any starts a shadow ray on the triangle that last occluded a ray of its wave; RT_OCCLUDER_CACHE=0 (read at
+    rt_commit) turns that off.  Same rays, same 8-bit image and ids; fewer node visits with the cache."""
+    from raytracer_amd.renderer import Renderer
+    scene = get_scene(name, False)
+
+    def render(on):
+        monkeypatch.setenv("RT_OCCLUDER_CACHE", str(on))
+        r = Renderer(0).set_scene(scene)
+        try:
+            return r.render(w, h, spp=spp, collect_stats=1)
+        finally:
+            r.close()
+
+    off, on = render(0), render(1)
+    assert np.array_equal(off["rgb8"], on["rgb8"]) and np.array_equal(off["primid"], on["primid"])
+    assert np.abs(off["rgbf"] - on["rgbf"]).max() <= 1e-3  # (bit-equal in practice; see DESIGN 3.1 for the caveat)
+    a, b = off["stats"], on["stats"]
+    for k in ("rays_shadow", "rays_closest", "hits_shaded", "shadow_culled"):
+        assert a[k] == b[k], k
+    print(f"{name}: shadow node visits {a['nodes_visited_any']} -> {b['nodes_visited_any']} with the cache, "
+          f"float pixels that differ: {int((off['rgbf'] != on['rgbf']).any(axis=-1).sum())}")
+    assert b["nodes_visited_any"] < a["nodes_visited_any"]
 
 
 def test_split_queue_without_room_changes_nothing(monkeypatch):
