@@ -518,11 +518,15 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // are mostly blocked by the same triangle: a new ray starts with the last occluder found in this wave as its
     // postponed leaf, i.e. it is tested in the ray's first triangle phase.  A hit ends the walk before it began; a miss
     // costs one triangle step (4K frame: k_any 282 -> 259 ms).  The cached test skips the box tests on the way to the
-    // triangle: where the reference's exact test accepts a triangle whose boxes the ray misses (grazing rays: the test
-    // does not check the distance to the plane), the answer depends on the cache, i.e. on scheduling.  Measured: no
-    // float bit of the 4K competition frame moves between runs; in the 4 M-triangle stress frame one pixel of 8.3 M
-    // does (8-bit images and counts identical).  RT_OCCLUDER_CACHE=0 (rt_commit) turns the cache off.
+    // triangle, so it is only as good as "boxes never cull what the exact test accepts": see the guard where the ray
+    // is taken.  -DRT_DEBUG_OCC builds a checker that ignores every cached hit, walks on and prints the rays whose walk
+    // finds no occluder (scripts/gpu_float_determinism.py compares float bits across runs); RT_OCCLUDER_CACHE=0
+    // (rt_commit) turns the cache off.
     uint32_t last_occ = RT_NODE_DONE;  // single-triangle leaf reference
+#ifdef RT_DEBUG_OCC
+    uint32_t dbg_ref = RT_NODE_DONE;   // the cached reference this ray started on
+    bool dbg_direct = false;           // ... and it hit, but the walk goes on to see whether it agrees
+#endif
     bool occ_new = false;              // found since the wave's last refill
     auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
         bool add = true;
@@ -647,7 +651,17 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 } else if (ANY) {
                     w.best_t = ldist;  // light distance
                     if (analyticOccluded(sc, an, w, ldist)) has = false;  // occluded: nothing to add
-                    if (sc.occluder_cache) w.pend = last_occ;
+                    // Not for rays that start far outside the scene (a horizon pixel on an infinite plane): there
+                    // the exact test's distance t is off by up to ~10^3 units for a triangle the ray grazes (t is a
+                    // quotient of two rounded dot products of |o|-sized terms), so it accepts triangles BEYOND the
+                    // light that the walk, whose boxes end at the light, never reaches -- the answer would depend on
+                    // what the cache holds (RT_DEBUG_OCC build: 7 such rays per stress frame, none with this guard).
+                    const bool near_scene = fmaxf(fmaxf(fabsf(w.r.o.x), fabsf(w.r.o.y)), fabsf(w.r.o.z)) <= 4.0f * sc.bound;
+                    if (sc.occluder_cache && near_scene) w.pend = last_occ;
+#ifdef RT_DEBUG_OCC
+                    dbg_ref = w.pend;
+                    dbg_direct = false;
+#endif
                 } else if (sample & RT_FLAG_INVALID) {  // slot of a pixel outside the image: recorded as a miss
                     w.best_t = INFINITY;
                     w.best_id = RT_ID_MISS;
@@ -694,8 +708,21 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
             } else if (nTri > 0) {
                 if (COUNT && atTri) walk++;
+#ifdef RT_DEBUG_OCC
+                bool dbg_first = ANY && !SPLIT && atTri && dbg_ref != RT_NODE_DONE && w.pend == dbg_ref;
+                if (dbg_first) dbg_ref = RT_NODE_DONE;
+                bool dbg_hit = atTri && rtTriStep<ANY, COUNT>(sc, w, st);
+                if (dbg_hit && dbg_first) {  // ignore the direct hit, remember it, walk on
+                    dbg_direct = true;
+                    dbg_hit = false;
+                    w.pend = RT_NODE_DONE;
+                }
+                if (dbg_hit) {
+                    has = false;
+#else
                 if (atTri && rtTriStep<ANY, COUNT>(sc, w, st)) {  // occluded: the pending radiance is dropped
                     has = false;
+#endif
                     if (ANY && !SPLIT) {
                         last_occ = w.pend & ~(7u << 28);  // the triangle alone, not the rest of its leaf
                         occ_new = true;
@@ -714,6 +741,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             if (has && w.cur == RT_NODE_DONE && w.pend == RT_NODE_DONE) {  // walk finished: result written at the next refill
                 fin = true;
                 has = false;
+#ifdef RT_DEBUG_OCC
+                if (ANY && !SPLIT && dbg_direct)
+                    printf("OCCHOLE ray %u tri %u o %.9g %.9g %.9g d %.9g %.9g %.9g ldist %.9g\n", ray_i, last_occ & RT_NODE_INDEX_MASK,
+                           w.r.o.x, w.r.o.y, w.r.o.z, w.r.d.x, w.r.d.y, w.r.d.z, w.best_t);
+#endif
             }
             ++iter;
         } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & period) != 0);

@@ -22,14 +22,16 @@ def renderer():
 
 
 def render_rank(rank, world, spp, **kw):
-    """this rank's tiles as (rgb8 [n,256,3], primid [n,256], stats) numpy arrays"""
+    """this rank's tiles as (rgb8 [n,256,3], primid [n,256], stats) device tensors; the float image goes to _r["f"]"""
     import torch
     r = renderer()
     n = r.tile_counts(W, H, rank, world)[0]
     t8 = torch.zeros(n, 256, 3, dtype=torch.uint8, device="cuda:0")
     tp = torch.zeros(n, 256, dtype=torch.int32, device="cuda:0")
-    st = r.render_tiles_device(W, H, rank, world, t8.data_ptr(), 0, tp.data_ptr(), spp=spp, **kw)
+    tf = torch.zeros(n, 256, 3, dtype=torch.float32, device="cuda:0")
+    st = r.render_tiles_device(W, H, rank, world, t8.data_ptr(), tf.data_ptr(), tp.data_ptr(), spp=spp, **kw)
     torch.cuda.synchronize()
+    _r["f"] = tf.view(torch.int32)  # float bits
     return t8, tp, st
 
 
@@ -57,8 +59,10 @@ def test_sampled_tiles_of_the_4k_frame_match_the_oracle(oracle_for):
 def test_full_frame_64spp_is_deterministic_chunk_and_partition_independent():
     import torch
     a8, ap, sa = render_rank(0, 1, 64)
+    af = _r["f"]
     b8, bp, sb = render_rank(0, 1, 64, chunk_samples=3 << 20)   # different chunking
     assert torch.equal(a8, b8) and torch.equal(ap, bp)
+    assert torch.equal(af, _r["f"])  # the float image too, bit for bit (work is fetched dynamically: no two runs schedule alike)
     assert sa["primary_samples"] == sb["primary_samples"] == W * H * 64
     for k in ("rays_closest", "rays_shadow", "shadow_culled", "hits_shaded"):
         assert sa[k] == sb[k], k
@@ -66,11 +70,13 @@ def test_full_frame_64spp_is_deterministic_chunk_and_partition_independent():
     assert sa["rays_closest"] >= sa["primary_samples"]
     # two-rank partition: every tile of the single-rank frame reappears bit for bit in its owner's buffer
     del b8, bp
+    _r.pop("f")
     world = 2
     tot = {k: 0 for k in ("rays_closest", "rays_shadow", "primary_samples")}
     for rank in range(world):
         r8, rp, sr = render_rank(rank, world, 64)
         assert torch.equal(r8, a8[rank::world]) and torch.equal(rp, ap[rank::world])
+        assert torch.equal(_r["f"], af[rank::world])
         for k in tot:
             tot[k] += sr[k]
         del r8, rp

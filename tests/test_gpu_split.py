@@ -52,7 +52,7 @@ def test_occluder_cache_changes_no_image(monkeypatch, name, w, h, spp):
 
     off, on = render(0), render(1)
     assert np.array_equal(off["rgb8"], on["rgb8"]) and np.array_equal(off["primid"], on["primid"])
-    assert np.abs(off["rgbf"] - on["rgbf"]).max() <= 1e-3  # (bit-equal in practice; see DESIGN 3.1 for the caveat)
+    assert np.array_equal(off["rgbf"].view(np.uint32), on["rgbf"].view(np.uint32))
     a, b = off["stats"], on["stats"]
     for k in ("rays_shadow", "rays_closest", "hits_shaded", "shadow_culled"):
         assert a[k] == b[k], k
