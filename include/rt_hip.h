@@ -208,7 +208,8 @@ int rt_tile_counts(int32_t width, int32_t height, int32_t rank, int32_t world, i
 /* Multi-GPU form: renders only this rank's interleaved tiles into DEVICE buffers in tile-major order
  * (local tile k = global tile k*world+rank; 256 pixels per tile, pixel (x,y) of the tile at y*16+x):
  * d_rgb8[n_local*256*3] u8, d_rgbf[n_local*256*3] f32, d_primid[n_local*256] u32 (any may be NULL).
- * Work is enqueued on `stream` (a hipStream_t, 0 = default) and is complete when the call returns. */
+ * Work is enqueued on `stream` (a hipStream_t; 0 = the context's own non-blocking stream, NOT the HIP default
+ * stream) and is complete when the call returns (the call synchronises that stream). */
 int rt_render_tiles_device(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8,
                            void *d_rgbf, void *d_primid, void *stream, rt_stats *stats);
 

@@ -178,6 +178,34 @@ RENDERS = [  # name, scene, w, h, spp, depth, seed
 ]
 
 
+# BASELINE.json configs 1 and 2 at their stated sizes: main.cpp as shipped (competition scene
+# minus pietre, 1024x768, 4 spp, main.cpp:543-545,555,625) and the sample scene at 1920x1080, 16 spp.  Minutes of
+# reference CPU time each, so they are made on request (--only full) and keep only what the acceptance test
+# compares: 8-bit image, primitive ids, invalid mask.
+FULLSIZE = [
+    ("full_competition_1024x768", "competition", 1024, 768, 4, 3, 0),
+    ("full_sample_1920x1080_spp16", "sample", 1920, 1080, 16, 3, 0),
+]
+
+
+def gen_fullsize(tmp, only=None):
+    for name, scene_name, w, h, spp, depth, seed in FULLSIZE:
+        if only not in (None, "full") and only != name:
+            continue
+        scene = FlatScene.builtin(scene_name, lazy=True)
+        pre = os.path.join(tmp, name)
+        info = run(O2, "render", scene_name, w, h, spp, depth, seed, pre, "ids")
+        rgb8 = np.fromfile(pre + ".rgb8.i32", np.int32).reshape(h, w, 3)
+        rgbf = np.fromfile(pre + ".rgbf.f32", np.float32).reshape(h, w, 3)
+        ids = np.fromfile(pre + ".ids.i32", np.int32).reshape(h, w, 2)
+        invalid = ((rgb8 < 0) | (rgb8 > 255)).any(axis=2) | np.isnan(rgbf).any(axis=2)
+        np.savez_compressed(os.path.join(GOLD, f"render_{name}.npz"), rgb8=np.clip(rgb8, 0, 255).astype(np.uint8),
+                            invalid=np.packbits(invalid), primid=ids_to_prim(ids, scene),
+                            params=json.dumps(dict(scene=scene_name, width=w, height=h, spp=spp, depth=depth, seed=seed,
+                                                   reference_render_s=info.get("render_s"), reference_threads=info.get("threads"))))
+        print(name, "O2 %.2fs" % info["render_s"], flush=True)
+
+
 def gen_renders(tmp, only=None):
     timing = {}
     for name, scene_name, w, h, spp, depth, seed in RENDERS:
@@ -221,6 +249,8 @@ def main():
             gen_scene_dump(tmp, "cones")
         if a.only == "rays_cones":
             gen_rays(tmp, "cones")
+        if a.only is not None and a.only.startswith("full"):
+            gen_fullsize(tmp, a.only)
         if a.only is None or a.only.startswith(("render", "sample", "competition", "bunny", "cones_")):
             t = gen_renders(tmp, None if a.only in (None, "render") else a.only)
             if a.only in (None, "render"):

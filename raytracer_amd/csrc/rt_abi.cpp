@@ -92,8 +92,7 @@ struct rt_context {
     DevBuf<uint8_t> d_bmp[4];
     RtSceneDev dev{};
     // wavefront workspace (sized for one chunk, reused across calls)
-    size_t ws_samples = 0;
-    int ws_fanout = 0, ws_lights = 0;
+    size_t ws_samples = 0, ws_bytes = 0;
     DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shC;
     DevBuf<float> d_rayR[2];
     DevBuf<float2> d_hits;
@@ -130,29 +129,44 @@ QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl)
     return z;
 }
 
+// rays of the deepest level per primary sample, worst case: every hit spawns a reflection/refraction pair (main.cpp:148-205)
+int worstFanout(int max_depth) { return 1 << std::min(std::max(max_depth, 0), 15); }
+
 int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights) {
-    const int fanout = 1 << std::min(std::max(max_depth, 0), 4);  // rays of the deepest level per primary sample (worst case)
-    n_lights = std::max(n_lights, 1);
-    if (samples <= ctx->ws_samples && fanout <= ctx->ws_fanout && n_lights <= ctx->ws_lights) return 0;
-    samples = std::max(samples, ctx->ws_samples);
-    const int fo = std::max(fanout, ctx->ws_fanout), nl = std::max(n_lights, ctx->ws_lights);
-    const QueueSizes z = queueSizes(ctx, samples, fo, nl);
-    const size_t ray_cap = z.ray_cap, sh_cap = z.sh_cap;
+    const QueueSizes z = queueSizes(ctx, samples, worstFanout(max_depth), std::max(n_lights, 1));
     if (!z.fits32) return fail("chunk too large: queue capacity exceeds 2^32 entries");
-    for (int k = 0; k < 2; k++) {
-        if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
-    }
-    if (ctx->d_hits.alloc(ray_cap + 1)) return 1;
-    if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
-    if (ctx->d_accum.alloc(samples * 3)) return 1;
-    if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
-    if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
+    if (samples <= ctx->ws_samples && z.ray_cap <= ctx->q.ray_cap && z.sh_cap <= ctx->q.shadow_cap) return 0;
+    // grow: capacities only ever go up (a later call with fewer samples but more bounces keeps the larger of each)
+    samples = std::max(samples, ctx->ws_samples);
+    const size_t ray_cap = std::max<size_t>(z.ray_cap, ctx->q.ray_cap), sh_cap = std::max<size_t>(z.sh_cap, ctx->q.shadow_cap);
+    // DevBuf::alloc frees before it allocates: after a failed grow some buffers are new, some are gone.  The
+    // workspace is then declared empty (sizes 0, queue pointers null), so that no later call takes the early return
+    // above and launches kernels on freed memory; the next call allocates from scratch.
+    auto grow = [&]() -> int {
+        for (int k = 0; k < 2; k++) {
+            if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
+        }
+        if (ctx->d_hits.alloc(ray_cap + 1)) return 1;
+        if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
+        if (ctx->d_accum.alloc(samples * 3)) return 1;
+        if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
+        if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
+        return 0;
+    };
     size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
     if (const char *e = getenv("RT_SPLIT_CAP")) split_cap = (size_t)std::max(64, atoi(e));  // (test knob: forces the no-room path)
-    if (ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) return 1;
+    if (grow() || ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) {
+        const std::string why = g_err;
+        for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); ctx->d_split[k].release(); }
+        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_resid.release();
+        ctx->ws_samples = 0;
+        ctx->ws_bytes = 0;
+        ctx->q = RtQueues{};
+        ctx->q.spill = ctx->d_spill.p;
+        return fail("workspace allocation failed (workspace released): " + why);
+    }
+    ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8) + sh_cap * 32 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
     ctx->ws_samples = samples;
-    ctx->ws_fanout = fo;
-    ctx->ws_lights = nl;
     RtQueues &q = ctx->q;
     for (int k = 0; k < 2; k++) {
         q.rayA[k] = ctx->d_rayA[k].p;
@@ -233,19 +247,19 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
 }
 
 // levels 0..max_depth of one chunk whose level-0 queue has already been filled
-void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
+void runLevels(rt_context *ctx, const RtQueues &q, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
                int stats, KernelTimer &kt, rt_stats *st, uint64_t level0_rays, bool level0_traced = false) {
     for (int level = 0; level <= max_depth; level++) {
         if (!(level == 0 && level0_traced)) {  // each level's queue is claimed once (dynamic fetch counters)
             kt.begin(1);
-            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
+            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats);
             kt.end();
         }
         kt.begin(2);
-        rtLaunchShade(cfg, ctx->dev, ctx->q, level, max_depth, spp, tile0, primid_tiles, stats >= 2, level0_rays << level);
+        rtLaunchShade(cfg, ctx->dev, q, level, max_depth, spp, tile0, primid_tiles, stats >= 2, level0_rays << level);
         kt.end();
         kt.begin(3);
-        rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, level, stats);
+        rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats);
         kt.end();
         if (st) {
             st->launches_closest++;
@@ -254,18 +268,16 @@ void runLevels(rt_context *ctx, const RtLaunchCfg &cfg, int max_depth, int spp, 
     }
 }
 
-int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *d_rgb8, float *d_rgbf,
-                uint32_t *d_primid, hipStream_t stream, rt_stats *stats) {
+// parameter checks + camera / image constants of the tile loop (main.cpp:561-563), shared by the render entry points
+int makeFrame(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, RtFrameDev &f, int &world) {
     if (!ctx->committed) return fail("rt_commit has not been called");
     if (p->width <= 0 || p->height <= 0 || p->spp <= 0 || p->max_depth < 0 || p->max_depth > 15)
         return fail("bad render parameters (width/height/spp > 0, 0 <= max_depth <= 15)");
-    const int world = p->tile_world > 0 ? p->tile_world : 1;
+    world = p->tile_world > 0 ? p->tile_world : 1;
     if (p->tile_rank < 0 || p->tile_rank >= world) return fail("tile_rank out of range");
     const bool table = p->jitter_mode == RT_JITTER_TABLE || (p->jitter_mode == RT_JITTER_AUTO && p->spp == 4);
     if (table && p->spp != 4) return fail("RT_JITTER_TABLE requires spp == 4 (reference jitterMatrix, main.cpp:601-606)");
-    if (bind(ctx)) return 1;
-
-    RtFrameDev f{};
+    f = RtFrameDev{};
     std::memcpy(f.origin, cam->origin, sizeof f.origin);
     std::memcpy(f.rot, cam->rot, sizeof f.rot);
     f.dz = cam->dz;
@@ -283,6 +295,15 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     f.tile_world = world;
     f.use_table = table ? 1 : 0;
     f.seed = p->seed;
+    return 0;
+}
+
+int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *d_rgb8, float *d_rgbf,
+                uint32_t *d_primid, hipStream_t stream, rt_stats *stats) {
+    RtFrameDev f{};
+    int world = 1;
+    if (makeFrame(ctx, cam, p, f, world)) return 1;
+    if (bind(ctx)) return 1;
 
     int64_t n_local = 0, n_total = 0;
     rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, &n_total);
@@ -290,13 +311,16 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 26;
     chunk_samples = std::min<size_t>(chunk_samples, RT_SAMPLE_MASK);
     if (p->chunk_samples <= 0) {
-        // default chunk: 64 Mi samples, halved until the queues' worst case fits 32-bit indices and 3/4 of the HBM
+        // default chunk: 64 Mi samples, halved until the queues' worst case fits 32-bit indices and 7/8 of the memory
+        // that is FREE on this device (torch, RCCL or other contexts may hold part of the HBM) plus what this
+        // context's workspace already holds
         size_t free_b = 0, total_b = 0;
         HIPOK(hipMemGetInfo(&free_b, &total_b));
-        const int fo = 1 << std::min(p->max_depth, 4), nl = std::max<int>(1, (int)ctx->lights.size());
+        const size_t budget = (free_b + ctx->ws_bytes) / 8 * 7;
+        const int fo = worstFanout(p->max_depth), nl = std::max<int>(1, (int)ctx->lights.size());
         while (chunk_samples > per_tile) {
             const QueueSizes z = queueSizes(ctx, chunk_samples, fo, nl);
-            if (z.fits32 && z.bytes <= total_b / 4 * 3) break;
+            if (z.fits32 && z.bytes <= budget) break;
             chunk_samples /= 2;
         }
     }
@@ -334,7 +358,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         kt.begin(0);
         rtLaunchGenPrimary(cfg, f, ctx->q, tile0, ntiles);
         kt.end();
-        runLevels(ctx, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)ntiles * per_tile);
+        runLevels(ctx, ctx->q, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)ntiles * per_tile);
         kt.begin(4);
         rtLaunchResolve(cfg, f, ctx->q, tile0, ntiles, d_rgb8, d_rgbf);
         kt.end();
@@ -443,6 +467,8 @@ int rt_set_triangles(rt_context *ctx, int64_t n, const float *v0, const float *v
     if (!ctx || n < 0) return fail("rt_set_triangles: bad arguments");
     if (n >= (1ll << 27)) return fail("rt_set_triangles: at most 2^27-1 triangles (28-bit record index: nodes + triangles)");
     if (n && (!v0 || !v1 || !v2 || !flags || !object_id)) return fail("rt_set_triangles: NULL vertex/flags/object arrays");
+    for (int64_t k = 1; k < n; k++)  // (validated before anything of the context changes)
+        if (object_id[k] < object_id[k - 1]) return fail("rt_set_triangles: object_id must be non-decreasing");
     auto put = [&](std::vector<float> &dst, const float *src, int w) {
         dst.assign((size_t)n * w, 0.0f);
         if (src && n) std::memcpy(dst.data(), src, (size_t)n * w * sizeof(float));
@@ -452,8 +478,6 @@ int rt_set_triangles(rt_context *ctx, int64_t n, const float *v0, const float *v
     put(ctx->tA, tA, 2); put(ctx->tB, tB, 2); put(ctx->tC, tC, 2);
     ctx->tri_flags.assign(flags, flags + n);
     ctx->tri_object.assign(object_id, object_id + n);
-    for (int64_t k = 1; k < n; k++)
-        if (object_id[k] < object_id[k - 1]) return fail("rt_set_triangles: object_id must be non-decreasing");
     ctx->committed = false;
     return 0;
 }
@@ -738,8 +762,21 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
     rt_stats local{};
     rt_stats *st = stats ? stats : &local;
     std::memset(st, 0, sizeof *st);
-    const size_t chunk = 1 << 20;
-    if (ensureWorkspace(ctx, std::min<size_t>(std::max<int64_t>(n, 1), chunk), depth, (int)ctx->lights.size())) return 1;
+    // rays per pass: 1 Mi, halved until the worst case of the deepest level (2^depth rays per input ray) fits 32-bit
+    // queue indices and the free memory
+    size_t chunk = std::min<size_t>(std::max<int64_t>(n, 1), (size_t)1 << 20);
+    {
+        size_t free_b = 0, total_b = 0;
+        HIPOK(hipMemGetInfo(&free_b, &total_b));
+        const size_t budget = (free_b + ctx->ws_bytes) / 8 * 7;
+        const int fo = worstFanout(depth), nl = std::max<int>(1, (int)ctx->lights.size());
+        while (chunk > 1) {
+            const QueueSizes z = queueSizes(ctx, chunk, fo, nl);
+            if (z.fits32 && z.bytes <= budget) break;
+            chunk /= 2;
+        }
+    }
+    if (ensureWorkspace(ctx, chunk, depth, (int)ctx->lights.size())) return 1;
     RtLaunchCfg cfg = ctx->cfg;
     cfg.stream = ctx->stream;
     DevBuf<float> d_rays, d_col;
@@ -758,7 +795,7 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
         // level 0 closest hit first: the hit records of the batch are reported from it
         rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, 0);
         if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
-        runLevels(ctx, cfg, depth, 1, 0, nullptr, 0, kt, st, m, true);
+        runLevels(ctx, ctx->q, cfg, depth, 1, 0, nullptr, 0, kt, st, m, true);
         rtLaunchBatchColors(cfg, ctx->q, m, d_col.p);
         std::vector<uint32_t> hc(RT_CNT_WORDS);
         e = hipStreamSynchronize(cfg.stream);

@@ -15,6 +15,9 @@ struct RtLaunchCfg {
     int analytic_bytes = 0;        // LDS behind the stack holding the staged spheres + planes
     int split_budget = 1024;       // wave iterations (a power of two) after which a shadow ray's walk is split into work items (0 = never)
     int trace_blocks_per_cu = 4;   // resident 256-thread blocks per CU for the traversal kernels (LDS-limited)
+    int shade_blocks = 0;          // k_shade grid in blocks; 0 = num_cus * RT_SHADE_BLOCKS_PER_CU (rt_render_tiles_static
+                                   // uses a small grid: every wave owns (lights + 1) output slabs, i.e. queue slack)
+    uint32_t shade_slab = 0;       // slots per slab; 0 = chosen from the level's size (rtLaunchShade)
 };
 
 void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles);
@@ -23,7 +26,8 @@ void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs);
 // waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)
-inline int rtShadeWaves(const RtLaunchCfg &cfg) { return cfg.num_cus * RT_SHADE_BLOCKS_PER_CU * (RT_BLOCK / 64); }
+inline int rtShadeBlocks(const RtLaunchCfg &cfg) { return cfg.shade_blocks > 0 ? cfg.shade_blocks : cfg.num_cus * RT_SHADE_BLOCKS_PER_CU; }
+inline int rtShadeWaves(const RtLaunchCfg &cfg) { return rtShadeBlocks(cfg) * (RT_BLOCK / 64); }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles);
 void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,

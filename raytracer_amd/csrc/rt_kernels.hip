@@ -493,6 +493,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     uint32_t iter = 0;                                     // wave iterations of the walk loop so far (uniform)
     // the wave passes the top of its outer loop (where long lanes are looked for) at least every period + 1 iterations
     const uint32_t period = (SPLIT && budget && budget < 1024u) ? budget - 1u : 1023u;  // budget is a power of two
+    bool can_export = true;                                // uniform: cleared when the round's item buffer is full
     bool occl = false;                                     // SPLIT: the finished item found a hit
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
@@ -553,7 +554,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     const unsigned long long tStart = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
         const unsigned long long tRefill = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (ANY && budget) {  // uniform
+        if (ANY && budget && can_export) {  // uniform
             const bool longLane = has && iter - age[laneNow()] > budget;
             if (__ballot(longLane)) {
                 const uint32_t lane = laneId();
@@ -578,7 +579,9 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     }
                 } else {  // no room: the rays walk on; the reserved slots inside the buffer must not hold garbage
                     for (uint32_t sl = base + lane; sl < min(base + total, q.split_cap); sl += 64) items_out[sl] = make_uint2(RT_SPLIT_NULL, RT_NODE_DONE);
-                    if (longLane) age[laneNow()] = iter;  // try again a budget later
+                    // The item buffer of this round is full and stays full: this wave stops exporting, so it bumps
+                    // the counter past the capacity at most once (retrying every `budget` iterations could wrap it)
+                    can_export = false;
                 }
             }
         }
@@ -796,6 +799,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
         if (!ANY) B = q.rayB[buf][i];
     }
     const bool hole = ANY && __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
+    if (hole) A.w = 0.0f;  // (a hole's word would decode to light 15: past the scene's light array)
     uint32_t sample = __float_as_uint(B.w);
     float ldist = 0.0f;
     if (ANY) {
@@ -1546,8 +1550,9 @@ void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues 
     const uint64_t waves = (uint64_t)rtShadeWaves(cfg);
     uint32_t slab = 64;
     while (slab < RT_SLAB_MAX && (uint64_t)slab * 16 * waves <= max_inputs) slab <<= 1;
-    if (prof) hipLaunchKernelGGL(k_shade<true>, dim3(gridFor(cfg, RT_SHADE_BLOCKS_PER_CU)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(gridFor(cfg, RT_SHADE_BLOCKS_PER_CU)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    if (cfg.shade_slab) slab = cfg.shade_slab;
+    if (prof) hipLaunchKernelGGL(k_shade<true>, dim3(rtShadeBlocks(cfg)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(rtShadeBlocks(cfg)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
 }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles) {

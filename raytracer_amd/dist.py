@@ -51,18 +51,42 @@ class DistributedFrame:
         self.r, self.W, self.H, self.rank, self.world, self.dist = renderer, width, height, rank, world, dist
         self.force_collective = force_collective  # run the gather even with one rank (rehearsal of the RCCL path)
         self.per = tiles_per_rank(width, height, world)
+        self.device = device
         self.t8 = torch.zeros(self.per, TILE_PIXELS, 3, dtype=torch.uint8, device=device)
         self.tp = torch.zeros(self.per, TILE_PIXELS, dtype=torch.int32, device=device)
+        self.collective = world > 1 or force_collective
         if rank == 0:
             self.o8 = torch.zeros(height, width, 3, dtype=torch.uint8, device=device)
             self.op = torch.zeros(height, width, dtype=torch.int32, device=device)
+            # receive buffers of the gather, allocated once ([world, ...]: the layout rt_assemble_tiles_device reads)
+            self.g8 = torch.empty((world,) + tuple(self.t8.shape), dtype=torch.uint8, device=device) if self.collective else None
+            self.gp = torch.empty((world,) + tuple(self.tp.shape), dtype=torch.int32, device=device) if self.collective else None
 
-    def render(self, stream=0, **kw):
-        """returns this rank's rt_stats dict; on rank 0 self.o8 / self.op hold the assembled image afterwards"""
+    def render(self, stream=None, **kw):
+        """returns this rank's rt_stats dict; on rank 0 self.o8 / self.op hold the assembled image afterwards.
+
+        Everything is ordered on ONE stream: torch's current stream of this rank's device unless `stream` (a raw
+        hipStream_t) is given -- the render and the assembly are enqueued on it through the C ABI, and the nccl backend
+        orders its gather against torch's current stream, so the caller must pass that very stream if it passes one.
+        (0 would mean the context's private non-blocking stream, which the gather is NOT ordered against.)"""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+            if self.device.type == "cuda" and stream == 0:
+                # torch's legacy default stream has handle 0, which the ABI reads as "context stream": render on the
+                # context stream then, and fence both ways around the gather with device synchronisation
+                torch.cuda.synchronize(self.device)
         st = self.r.render_tiles_device(self.W, self.H, self.rank, self.world, self.t8.data_ptr(), 0, self.tp.data_ptr(),
-                                        stream=stream, **kw)
-        g = gather_tiles([self.t8, self.tp], self.rank, self.world, self.dist, self.force_collective)
+                                        stream=stream, **kw)   # (complete when the call returns)
+        if not self.collective:
+            g8, gp = self.t8, self.tp
+        else:
+            self.dist.gather(self.t8, list(self.g8.unbind(0)) if self.rank == 0 else None, dst=0)
+            self.dist.gather(self.tp, list(self.gp.unbind(0)) if self.rank == 0 else None, dst=0)
+            g8, gp = (self.g8, self.gp) if self.rank == 0 else (None, None)
+            if stream == 0 and self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)  # the assembly below runs on the context stream: wait for the gather
         if self.rank == 0:
-            self.r.assemble_tiles_device(self.W, self.H, self.world, self.per, g[0].data_ptr(), 0, g[1].data_ptr(),
+            self.r.assemble_tiles_device(self.W, self.H, self.world, self.per, g8.data_ptr(), 0, gp.data_ptr(),
                                          self.o8.data_ptr(), 0, self.op.data_ptr(), stream=stream)
         return st

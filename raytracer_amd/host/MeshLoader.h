@@ -124,4 +124,5 @@ public:
         }
     }
     void flatten(FlatScene &out, int object_id) const override;
+    uint64_t geometryKey() const override;
 };

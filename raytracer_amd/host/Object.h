@@ -2,6 +2,7 @@
 // colour and material.  Objects are *descriptions*: intersection runs on the GPU (csrc/rt_kernels.hip), so
 // instead of a virtual intersect() each object knows how to append itself to a FlatScene.
 #pragma once
+#include <cstdint>
 #include "Core.h"
 #include "Material.h"
 
@@ -32,4 +33,6 @@ public:
 
     // appends this object's primitives; object_id is its position in the scene's object list
     virtual void flatten(FlatScene &out, int object_id) const = 0;
+    // what of the object's own geometry the uploaded-scene fingerprint must see beyond material and transformation
+    virtual uint64_t geometryKey() const { return 0; }
 };

@@ -22,6 +22,7 @@ public:
     glm::vec3 getNormal() const { return normal; }
     glm::vec3 getPoint() const { return point; }
     void flatten(FlatScene &out, int object_id) const override;
+    uint64_t geometryKey() const override;
 };
 
 // Unit cone (apex at the origin, opening towards +y, closed by the disc y = 1) under the object's transformation

@@ -169,20 +169,83 @@ rt_context *defaultContext() {
 }
 
 // ---- render()/trace_ray(): the GPU stands where the tile loop stood ----------------------------------
-static const void *g_uploaded_key = nullptr;
-static size_t g_uploaded_count = 0;
+// The uploaded scene is keyed on a fingerprint of everything the flattening reads: the object list (identity and
+// order), every object's material and transformation, its geometry key (plane: point + normal; mesh: triangle
+// storage + count + first/last triangle), the lights, ambient_light and the texture directory.  Editing any of
+// these between two render()/trace_ray() calls re-uploads; in-place edits of a mesh's inner triangles (which the
+// surface does not offer) need invalidateScene().
+static uint64_t g_uploaded_print = 0;
+static bool g_uploaded = false;
+static std::string g_texture_dir = "./textures";
+namespace {
+struct Fnv {
+    uint64_t h = 1469598103934665603ull;
+    void bytes(const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t k = 0; k < n; k++) h = (h ^ b[k]) * 1099511628211ull;
+    }
+    template <class T> void pod(const T &v) { bytes(&v, sizeof v); }
+};
+}  // namespace
+uint64_t Plane::geometryKey() const {
+    Fnv f;
+    f.pod(point.x); f.pod(point.y); f.pod(point.z);
+    f.pod(normal.x); f.pod(normal.y); f.pod(normal.z);
+    return f.h;
+}
+uint64_t MeshLoader::geometryKey() const {
+    Fnv f;
+    const size_t n = triangles.size();
+    const void *store = (const void *)triangles.data();
+    f.pod(n);
+    f.pod(store);
+    if (n) {
+        for (const Triangle *t : {&triangles.front(), &triangles.back()}) {
+            f.pod(t->vertexA.x); f.pod(t->vertexA.y); f.pod(t->vertexA.z);
+            f.pod(t->vertexC.x); f.pod(t->vertexC.y); f.pod(t->vertexC.z);
+        }
+    }
+    return f.h;
+}
+static uint64_t sceneFingerprint(const std::string &texture_dir) {
+    Fnv f;
+    FlatScene mats;  // materials go through the same conversion as the upload (function pointers -> texture ids)
+    f.pod(objects.size());
+    for (const Object *o : objects) {
+        const void *id = (const void *)o;
+        f.pod(id);
+        const int m = mats.addMaterial(o->material);
+        f.pod(m);
+        const glm::mat4 &t = o->getTransformation();
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) f.pod(t[c][r]);
+        f.pod(o->geometryKey());
+    }
+    for (const rt_material &m : mats.materials) f.pod(m);
+    f.pod(lights.size());
+    for (const Light *l : lights) {
+        f.pod(l->position.x); f.pod(l->position.y); f.pod(l->position.z);
+        f.pod(l->color.x); f.pod(l->color.y); f.pod(l->color.z);
+    }
+    f.pod(ambient_light.x); f.pod(ambient_light.y); f.pod(ambient_light.z);
+    f.bytes(texture_dir.data(), texture_dir.size());
+    return f.h;
+}
+void invalidateScene() { g_uploaded = false; }
+void setTextureDir(const std::string &dir) { g_texture_dir = dir; }
 static void ensureUploaded(rt_context *ctx, const std::string &texture_dir) {
-    // re-upload whenever the object list changed identity/size (cheap heuristic; clearScene() resets it)
-    if (g_uploaded_key == (const void *)objects.data() && g_uploaded_count == objects.size() + 1000003 * lights.size()) return;
+    const uint64_t print = sceneFingerprint(texture_dir);
+    if (g_uploaded && print == g_uploaded_print) return;
     FlatScene s = flattenScene(objects, lights, ambient_light);
     uploadScene(ctx, s, texture_dir);
     rt_set_host_texture_context(ctx);
-    g_uploaded_key = (const void *)objects.data();
-    g_uploaded_count = objects.size() + 1000003 * lights.size();
+    g_uploaded_print = print;
+    g_uploaded = true;
 }
 
 rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
     rt_context *ctx = defaultContext();
+    g_texture_dir = opt.textureDir;  // trace_ray()/trace_rays() after a render() read the same maps
     ensureUploaded(ctx, opt.textureDir);
     rt_render_params p{};
     p.width = image.getWidth();
@@ -203,7 +266,7 @@ rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
 
 std::vector<glm::vec3> trace_rays(const std::vector<Ray> &rays, int bounces, std::vector<Hit> *hits) {
     rt_context *ctx = defaultContext();
-    ensureUploaded(ctx, "./textures");
+    ensureUploaded(ctx, g_texture_dir);  // the directory of the last render(), or setTextureDir(); default ./textures
     const size_t n = rays.size();
     std::vector<float> in(6 * n), col(3 * n);
     for (size_t k = 0; k < n; k++) {
@@ -242,6 +305,5 @@ void clearScene() {
     objects.clear();
     lights.clear();
     ambient_light = glm::vec3(0.7f);
-    g_uploaded_key = nullptr;
-    g_uploaded_count = 0;
+    g_uploaded = false;
 }

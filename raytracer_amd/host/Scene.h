@@ -96,3 +96,8 @@ Camera competitionScene(const std::string &meshDir = "./meshes");    // main.cpp
 Camera coneScene(const std::string &meshDir = "./meshes");             // Cone test scene (oracle/ref_harness.cpp: cones_scene)
 Camera stressScene(const std::string &meshDir, int replicas);        // competition meshes on a lattice
 void clearScene();
+// render()/trace_ray() re-upload the globals whenever their fingerprint changes (objects, materials, transformations,
+// lights, ambient_light, texture directory); invalidateScene() forces it for edits the fingerprint cannot see.
+void invalidateScene();
+// directory of the four BMP maps (Textures.h:168-171) for trace_ray()/trace_rays(); render() takes RenderOptions::textureDir
+void setTextureDir(const std::string &dir);

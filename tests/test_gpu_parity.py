@@ -95,6 +95,27 @@ def test_render_against_reference(name):
     assert out["stats"]["queue_overflow"] == 0
 
 
+@pytest.mark.parametrize("name", ["full_competition_1024x768", "full_sample_1920x1080_spp16"])
+def test_baseline_configs_at_stated_size_against_reference(name):
+    """BASELINE.json configs[0] (main.cpp as shipped, minus the missing pietre.obj: 1024x768, 4 spp, main.cpp:543-545,
+    625) and configs[1] (sample scene 1920x1080, 16 spp) at their stated sizes, against goldens rendered by the COMPILED
+    REFERENCE (oracle/make_golden.py --only full: 355 s and 189 s of reference time on 8 cores), at the acceptance bar."""
+    g = load_golden("render_" + name)
+    p = render_params(g)
+    w, h = p["width"], p["height"]
+    invalid = np.unpackbits(g["invalid"])[:w * h].reshape(h, w).astype(bool)
+    out = renderer_for(p["scene"]).render(w, h, spp=p["spp"], max_depth=p["depth"], seed=p["seed"], want=("rgb8", "primid"))
+    ids = (out["primid"] == g["primid"]).mean()
+    frac, psnr = image_metrics(out["rgb8"], g["rgb8"], invalid)
+    worse = int((np.abs(out["rgb8"].astype(int) - g["rgb8"].astype(int)).max(axis=2) > 1).sum())
+    print(f"{name}: primid {ids:.6f} rgb8<=1 {frac:.6f} ({worse} px differ by > 1, {int(invalid.sum())} invalid in the reference) psnr {psnr:.2f} dB, "
+          f"GPU {out['stats']['ms_total']:.1f} ms vs reference {p['reference_render_s']:.1f} s on {p['reference_threads']} threads")
+    assert ids >= 0.9999
+    assert frac >= 0.999
+    assert psnr >= 50.0
+    assert out["stats"]["queue_overflow"] == 0
+
+
 @pytest.mark.parametrize("scene,w,h", [("sample", 200, 150), ("competition", 128, 96)])
 def test_ray_counts_match_oracle(scene, w, h, oracle_for):
     """a ray = one traced closest-hit or shadow query; counts are a property of the algorithm"""
