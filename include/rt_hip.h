@@ -213,6 +213,21 @@ int rt_tile_counts(int32_t width, int32_t height, int32_t rank, int32_t world, i
 int rt_render_tiles_device(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8,
                            void *d_rgbf, void *d_primid, void *stream, rt_stats *stats);
 
+/* rt_render_tiles_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE (its loop allocates freely on the host).
+ * Same inputs and outputs as rt_render_tiles_device, bit-identical results; the wavefront queues, counters and sample
+ * accumulators live in a 64 MiB `static __device__` array of the library (one per GPU, held until the process ends)
+ * instead of a workspace sized to the frame, so the frame is rendered in as many chunks of whole tiles as that array
+ * dictates (slower than rt_render_tiles_device: short launches).  The call makes no hipMalloc / hipFree / event or
+ * stream creation, does not synchronise and returns no statistics: work is enqueued on `stream` (0 = the context's
+ * stream) and the outputs are complete when the stream reaches the end of it.  Limits: one 16x16 tile at the given
+ * spp / max_depth / light count must fit the array (e.g. up to ~100 spp at depth 3 with 4 lights; depth <= 6 at
+ * 4 spp), otherwise the call fails with a message.  Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU (two streams, two contexts, two threads) race -- serialise them.  Scene-sized buffers (BVH, traversal
+ * spill area) were allocated by rt_commit. */
+int rt_render_tiles_static(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8,
+                           void *d_rgbf, void *d_primid, void *stream);
+
 /* Assembles the image on the gathering rank: d_tiles_* hold the ranks' tile-major buffers back to back in rank
  * order (exactly what an RCCL gather of rt_render_tiles_device outputs yields, ranks padded to `tiles_per_rank`
  * tiles each); outputs are row-major device images.  No counterpart in the reference (single process). */

@@ -106,6 +106,7 @@ def hip_lib():
     lib.rt_render.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, P(Stats)]
     lib.rt_tile_counts.argtypes = [I32, I32, I32, I32, P(I64), P(I64)]
     lib.rt_render_tiles_device.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, VP, P(Stats)]
+    lib.rt_render_tiles_static.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, VP]
     lib.rt_assemble_tiles_device.argtypes = [VP, I32, I32, I32, I64, VP, VP, VP, VP, VP, VP, VP]
     lib.rt_trace_batch.argtypes = [VP, I64, VP, I32, VP, VP, VP, P(Stats)]
     lib.rt_eval_texture.argtypes = [VP, I32, I64, VP, VP]

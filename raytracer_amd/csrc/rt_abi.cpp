@@ -9,11 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "rt_bvh.h"
 #include "rt_kernels.h"
+
+#define RT_SCRATCH_MAX_DEVICES 64
 
 namespace {
 
@@ -99,6 +102,9 @@ struct rt_context {
     DevBuf<long long> d_accum;
     DevBuf<uint32_t> d_counters, d_chunk_counters;
     RtQueues q{};
+    // the library's static scratch on this context's device (rt_render_tiles_static); resolved at rt_create
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
     // tile-major outputs of rt_render
     DevBuf<uint8_t> d_t8, d_o8;
     DevBuf<float> d_tf, d_of;
@@ -419,6 +425,28 @@ int rt_create(int device_id, rt_context **out) {
         delete ctx;
         return fail("rt_create: hipStreamCreate failed");
     }
+    {   // address of the static scratch on THIS device (looked up once per device, with that device current)
+        static std::mutex mu;
+        static void *table[RT_SCRATCH_MAX_DEVICES];
+        static size_t bytes = 0;
+        std::lock_guard<std::mutex> g(mu);
+        if (device_id >= RT_SCRATCH_MAX_DEVICES) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail("rt_create: device_id beyond the static-scratch table");
+        }
+        if (!table[device_id]) {
+            const char *why = "";
+            if (rtScratchResolve(&table[device_id], &bytes, &why)) {
+                table[device_id] = nullptr;
+                (void)hipStreamDestroy(ctx->stream);
+                delete ctx;
+                return fail(std::string("rt_create: hipGetSymbolAddress(rt_static_scratch): ") + why);
+            }
+        }
+        ctx->scratch = table[device_id];
+        ctx->scratch_bytes = bytes;
+    }
     *out = ctx;
     return 0;
 }
@@ -727,6 +755,92 @@ int rt_assemble_tiles_device(rt_context *ctx, int32_t width, int32_t height, int
     cfg.stream = stream ? (hipStream_t)stream : ctx->stream;
     rtLaunchAssemble(cfg, width, height, world, tiles_per_rank, t8, tf, tp, o8, of, op);
     HIPOK(hipStreamSynchronize(cfg.stream));
+    HIPOK(hipGetLastError());
+    return 0;
+}
+
+// ---- rt_render_tiles_static: the render loop on the library's static scratch, allocating nothing ----------------
+namespace {
+#define RT_STATIC_SHADE_BLOCKS 64   // k_shade grid of the static path: 256 waves, each owning (lights + 1) output slabs
+#define RT_STATIC_SLAB 64u          // slots per shadow slab (ray slabs: 128)
+#define RT_STATIC_SPLIT_CAP 65536u  // work items of split any-hit walks per round
+// carves the queues of `samples` primary samples out of [base, base + bytes); returns false if they do not fit
+bool carveStatic(unsigned char *base, size_t bytes, size_t samples, int fanout, int nl, uint32_t *spill, RtQueues &q) {
+    const size_t waves = (size_t)RT_STATIC_SHADE_BLOCKS * (RT_BLOCK / 64);
+    const size_t total = samples * (size_t)fanout;
+    const size_t ray_cap = total + waves * 128 + total / 64 + 128;            // as queueSizes(), with this path's slab sizes
+    const size_t sh_cap = total * nl + waves * nl * RT_STATIC_SLAB;
+    if (ray_cap >= (1ull << 31) || sh_cap >= (1ull << 31)) return false;
+    size_t off = 0;
+    auto take = [&](size_t n) -> void * {
+        void *p = base + off;
+        off += (n + 255) / 256 * 256;
+        return p;
+    };
+    q = RtQueues{};
+    q.counters = (uint32_t *)take(RT_CNT_WORDS * sizeof(uint32_t));
+    for (int k = 0; k < 2; k++) {
+        q.rayA[k] = (float4 *)take(ray_cap * sizeof(float4));
+        q.rayB[k] = (float4 *)take(ray_cap * sizeof(float4));
+        q.rayR[k] = (float *)take(ray_cap * sizeof(float));
+        q.split[k] = (uint2 *)take(RT_STATIC_SPLIT_CAP * sizeof(uint2));
+    }
+    q.hits = (float2 *)take((ray_cap + 1) * sizeof(float2));
+    q.shA = (float4 *)take(sh_cap * sizeof(float4));
+    q.shC = (float4 *)take(sh_cap * sizeof(float4));
+    q.accum = (long long *)take(samples * 3 * sizeof(long long));
+    q.resid = (uint32_t *)take(std::max(sh_cap, ray_cap) * sizeof(uint32_t));
+    q.spill = spill;
+    q.ray_cap = (uint32_t)ray_cap;
+    q.shadow_cap = (uint32_t)sh_cap;
+    q.split_cap = RT_STATIC_SPLIT_CAP;
+    return off <= bytes;
+}
+}  // namespace
+
+int rt_render_tiles_static(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8, void *d_rgbf,
+                           void *d_primid, void *stream_) {
+    if (!ctx || !cam || !p) return fail("rt_render_tiles_static: NULL argument");
+    RtFrameDev f{};
+    int world = 1;
+    if (makeFrame(ctx, cam, p, f, world)) return 1;
+    if (bind(ctx)) return 1;
+    if (!ctx->scratch) return fail("rt_render_tiles_static: the static scratch was not resolved on this device");
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
+    int64_t n_local = 0;
+    rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, nullptr);
+    const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
+    const int fo = worstFanout(p->max_depth), nl = std::max<int>(1, (int)ctx->lights.size());
+    // whole tiles per chunk: as many as the scratch holds (binary search on the carve)
+    RtQueues q{};
+    size_t lo = 0, hi = std::max<int64_t>(n_local, 1);
+    while (lo < hi) {
+        const size_t mid = (lo + hi + 1) / 2;
+        RtQueues t;
+        if (mid * per_tile <= RT_SAMPLE_MASK && carveStatic((unsigned char *)ctx->scratch, ctx->scratch_bytes, mid * per_tile, fo, nl, ctx->d_spill.p, t)) lo = mid;
+        else hi = mid - 1;
+    }
+    if (lo == 0)
+        return fail("rt_render_tiles_static: one 16x16 tile at " + std::to_string(p->spp) + " spp, depth " + std::to_string(p->max_depth) +
+                    " with " + std::to_string(nl) + " lights does not fit the " + std::to_string(ctx->scratch_bytes >> 20) +
+                    " MiB static scratch (lower spp or max_depth, or use rt_render_tiles_device)");
+    const size_t chunk_tiles = lo;
+    carveStatic((unsigned char *)ctx->scratch, ctx->scratch_bytes, chunk_tiles * per_tile, fo, nl, ctx->d_spill.p, q);
+    RtLaunchCfg cfg = ctx->cfg;
+    cfg.stream = stream;
+    cfg.shade_blocks = RT_STATIC_SHADE_BLOCKS;
+    cfg.shade_slab = RT_STATIC_SLAB;
+    KernelTimer kt;  // (off)
+    if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
+    for (size_t t0 = 0; t0 < (size_t)n_local; t0 += chunk_tiles) {
+        const uint32_t ntiles = (uint32_t)std::min<size_t>(chunk_tiles, (size_t)n_local - t0);
+        // the scratch keeps the last call's contents: the counters must start at zero (queue lengths, work cursors);
+        // queues and accumulators are written before they are read (level-0 k_shade stores every sample slot)
+        HIPOK(hipMemsetAsync(q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
+        rtLaunchGenPrimary(cfg, f, q, (uint32_t)t0, ntiles);
+        runLevels(ctx, q, cfg, p->max_depth, p->spp, (uint32_t)t0, (uint32_t *)d_primid, 0, kt, nullptr, (uint64_t)ntiles * per_tile);
+        rtLaunchResolve(cfg, f, q, (uint32_t)t0, ntiles, (uint8_t *)d_rgb8, (float *)d_rgbf);
+    }
     HIPOK(hipGetLastError());
     return 0;
 }

@@ -38,3 +38,9 @@ void rtLaunchRaysFromHost(const RtLaunchCfg &cfg, const float *d_rays, uint32_t 
 void rtLaunchBatchColors(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t n, float *d_out);
 void rtLaunchEvalTexture(const RtLaunchCfg &cfg, const RtSceneDev &sc, int id, long long n, const float *d_uv, float *d_out);
 void rtLaunchEvalPerlin(const RtLaunchCfg &cfg, long long n, const float *d_p, float *d_out);
+
+// The library's static scratch (rt_kernels.hip): a file-scope __device__ array that rt_render_tiles_static carves its
+// wavefront queues from, so that the call allocates nothing.  rtScratchResolve looks up the array's address on the
+// CURRENT device (every GPU holds its own copy at its own address) -- called once per device by rt_create.
+#define RT_STATIC_SCRATCH_BYTES (64ull << 20)
+int rtScratchResolve(void **ptr, size_t *bytes, const char **err);

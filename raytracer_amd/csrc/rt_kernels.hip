@@ -1580,3 +1580,22 @@ void rtLaunchEvalTexture(const RtLaunchCfg &cfg, const RtSceneDev &sc, int id, l
 void rtLaunchEvalPerlin(const RtLaunchCfg &cfg, long long n, const float *d_p, float *d_out) {
     hipLaunchKernelGGL(k_eval_perlin, dim3(gridFor(cfg, 2)), dim3(RT_BLOCK), 0, cfg.stream, n, d_p, d_out);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Static scratch of rt_render_tiles_static (include/rt_hip.h): the wavefront workspace of a caller that cannot
+// allocate.  In host code the array's NAME is only a stand-in for the symbol, never a device address: the address on
+// the current device comes from hipGetSymbolAddress, once per device (rt_create), and host code passes that pointer
+// -- to kernels (inside RtQueues), to hipMemsetAsync -- wherever it needs the array's memory.
+static __device__ __align__(256) unsigned char rt_static_scratch[RT_STATIC_SCRATCH_BYTES];
+
+int rtScratchResolve(void **ptr, size_t *bytes, const char **err) {
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(rt_static_scratch));
+    if (e != hipSuccess || !p) {
+        if (err) *err = e != hipSuccess ? hipGetErrorString(e) : "hipGetSymbolAddress returned a null address";
+        return 1;
+    }
+    *ptr = p;
+    *bytes = RT_STATIC_SCRATCH_BYTES;
+    return 0;
+}
