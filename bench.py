@@ -12,10 +12,12 @@ N > 1 is launched by the driver with torch.distributed.run (one process per GPU)
 interleaved over the ranks (tile t -> rank t % N), scene + BVH replicated, one gather at frame end ("strong"
 scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
 
-`roofline` is reported for the dominant kernel (k_closest or k_any, whichever took longer): algorithmic bytes
-(64 B per 4-wide BVH node or triangle record fetched + the ray's queue record, counted in-kernel) over its summed launch time
-measured with HIP events on the launch stream, against 8 TB/s HBM.  The working set of this scene is cache resident,
-so the fraction is expected to be small; `roofline_valu` prices the same kernel against the FP32 vector peak.
+`roofline` is reported for the dominant kernel (k_closest or k_any, whichever took longer).  Nothing on this path is a
+dense contraction and the scene's records are cache resident, so the binding ceiling is the FP32 vector unit
+(157.3 TFLOP/s): flops = 80 per 4-wide node step + 80 per triangle test, counted in-kernel in this run, over the kernel's
+summed launch time measured with HIP events on the launch stream.  Its HBM side (queue records + accumulator updates)
+sits next to it under `roofline.hbm`; `roofline.traffic` is only filled from a committed rocprofv3 --pmc pass when that
+pass was collected on the same kernel sources (hash).
 `cpu_baseline` is the compiled reference (oracle/_ref, `g++ -Ofast -fopenmp`) on a bounded sample of the same scene.
 """
 import argparse
@@ -98,7 +100,12 @@ def main():
     from raytracer_amd.dist import DistributedFrame, tile_counts
     n_tiles = tile_counts(W, H, 0, 1)[1]
     df = DistributedFrame(r, W, H, rank, world, dev, dist, force_collective=a.force_dist)   # tile-major device buffers owned by torch
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit stream for render, gather and assembly: torch's legacy default stream has handle 0, which the C ABI reads
+    # as "the context's own stream" -- the RCCL gather (ordered against torch's CURRENT stream) would then not be ordered
+    # against the render / assembly kernels
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
 
     def frame(collect=0):
         # own tiles -> RCCL gather of the tile-major buffers over xGMI -> de-interleave on rank 0
@@ -141,63 +148,73 @@ def main():
             "ms_per_frame": dt / max(a.steps, 1) * 1e3, "bvh": {"nodes": st["bvh_nodes"], "depth": st["bvh_depth"]},
         }
     if rank == 0 and not a.no_roofline:
+        from raytracer_amd._native import kernel_source_hash
         timed = frame(collect=2)       # per-kernel-class HIP-event timing on the launch stream
         counted = frame(collect=1)     # in-kernel record counters (stats build of the same kernels, counts only)
         pc, pa = counted["prof_packet_closest"], counted["prof_packet_any"]
-        # 64-byte records fetched: per-lane kernels count one per lane step, packet kernels one 128-byte node (two
-        # records) or one triangle record per WAVE step
+        # records fetched, counted in-kernel in THIS run: (ms, launches, node steps, triangle steps, rays)
         kinds = {
-            "k_closest": (timed["ms_closest"], timed["launches_closest"], counted["nodes_visited"] + 2 * pc[1],
-                          counted["tris_tested"] + pc[3], counted["rays_closest"], 40.0),
-            "k_any": (timed["ms_any"], timed["launches_any"], counted["nodes_visited_any"] + 2 * pa[1],
-                      counted["tris_tested_any"] + pa[3], counted["rays_shadow"], 48.0),
+            "k_closest": (timed["ms_closest"], timed["launches_closest"], counted["nodes_visited"], counted["tris_tested"], counted["rays_closest"]),
+            "k_any": (timed["ms_any"], timed["launches_any"], counted["nodes_visited_any"], counted["tris_tested_any"], counted["rays_shadow"]),
         }
         name = max(kinds, key=lambda k: kinds[k][0])
-        ms, launches, nodes, tris, nrays, ray_bytes = kinds[name]
+        ms, launches, nodes, tris, nrays = kinds[name]
         launches = max(launches, 1)
-        abytes = 64.0 * nodes + 64.0 * tris + ray_bytes * nrays   # algorithmic bytes per ray
-        flops = 80.0 * nodes + 80.0 * tris                         # four slab tests per node, SURVEY.md 8(d)
-        ach = abytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same workload
-            t = json.load(open(tpath))
-            if t.get("workload") == result["config"]["workload"] and name in t.get("kernels", {}):
-                traffic = t["kernels"][name]["hbm_bytes_per_launch"]
-        result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                              "bytes_per_launch": abytes / launches, "avg_launch_ms": ms / launches, "launches": launches,
-                              "records_per_ray": (nodes + tris) / max(nrays, 1),
-                              "note": "scene records are cache resident: achieved counts algorithmic record fetches, "
-                                      "traffic the HBM side (queues); see roofline_valu for the binding ceiling"}
+        # 20 flop per slab test x 4 child boxes of a 4-wide node, 80 per reference-formulation triangle test
+        flops = 80.0 * nodes + 80.0 * tris
         tf = flops / (ms / 1e3) / 1e12 if ms > 0 else 0.0
-        result["roofline_valu"] = {"kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
-                                   "note": "80 flop per 4-wide node (4 slab tests) + 80 per triangle test (SURVEY.md 8(d))"}
+        # the HBM side of the same kernel: its records are cache resident (5.4 MB scene), what streams is the queue --
+        # k_any: 16 B shadow record per ray + (16 B pending colour + 3 x 8 B accumulator update) per ray that reaches its
+        # light; k_closest: 32 B ray record + 8 B hit record per ray
+        if name == "k_any":
+            qbytes = 16.0 * nrays + 40.0 * counted["shadow_unoccluded"]
+        else:
+            qbytes = 40.0 * nrays
+        khash = kernel_source_hash()
+        traffic, traffic_src = None, "no rocprofv3 --pmc pass of these kernel sources is committed"
+        tpath = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes of this workload
+            t = json.load(open(tpath))
+            if t.get("kernel_source_hash") != khash:
+                traffic_src = "profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): not used"
+            elif t.get("workload") == result["config"]["workload"] and name in t.get("kernels", {}):
+                traffic = t["kernels"][name]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r02_pmc_traffic.json (same kernel sources, hash %s)" % khash
+        result["roofline"] = {
+            "kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "flops_per_launch": flops / launches, "avg_launch_ms": ms / launches, "launches": launches,
+            "records_per_ray": (nodes + tris) / max(nrays, 1), "kernel_source_hash": khash,
+            "hbm": {"algorithmic_bytes_per_launch": qbytes / launches, "achieved_GBs": qbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0,
+                    "peak_GBs": HBM_PEAK_GBS, "frac": qbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                    "note": "queue records + accumulator updates only; BVH / triangle records are L2 / Infinity Cache resident"},
+            "note": "no dense contraction on this path (SURVEY.md 8d): the ceiling is the FP32 vector unit; flops = 80 per 4-wide "
+                    "node step + 80 per triangle test, both counted in-kernel in this run"}
         pr = counted["prof_any" if name == "k_any" else "prof_closest"]  # counted in-kernel (cheap statistics build)
         if pr[2] and pr[5] and pr[8]:
-            result["roofline_valu"]["lanes"] = {
+            result["roofline"]["lanes"] = {
                 "lanes_per_node_phase": pr[3] / pr[2], "lanes_per_triangle_phase": pr[6] / pr[5],
                 "node_phases": pr[2], "triangle_phases": pr[5], "rays_per_refill": pr[9] / pr[8],
                 "note": "of 64 lanes; a phase issues its instructions for the whole wave"}
-        vpath = os.path.join(REPO, "profiles", "r01_pmc_valu.json")
-        if os.path.exists(vpath):  # committed rocprofv3 --pmc SQ_INSTS_VALU pass of this workload + the opcode micro-benchmark
-            v = json.load(open(vpath)).get("kernels", {}).get(name)
-            if v and v.get("SQ_INSTS_VALU"):
-                per_ray = v["SQ_INSTS_VALU"] / max(nrays, 1)
-                result["roofline_valu"]["issue"] = {
-                    "valu_wave_insts_per_ray": per_ray,
-                    "simd_cycles_per_valu_inst": (ms / 1e3) * 2.4e9 * 1024 / (per_ray * nrays),
-                    "note": "instruction count per ray from profiles/r01_pmc_valu.json x this run's time, 1024 SIMDs at 2.4 GHz; "
-                            "the node step's opcode mix costs ~3.7 cycles per instruction (profiles/r01_valu_issue.md): the "
-                            "closer this figure is to 3.7, the closer the kernel is to the SIMDs' issue limit"}
-        result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
+        vpath = os.path.join(REPO, "profiles", "r02_pmc_valu.json")
+        if os.path.exists(vpath):  # committed rocprofv3 --pmc SQ pass of this workload: only with matching kernel sources
+            vj = json.load(open(vpath))
+            v = vj.get("kernels", {}).get(name)
+            if vj.get("kernel_source_hash") == khash and v and v.get("SQ_INSTS_VALU"):
+                result["roofline"]["issue"] = {
+                    "valu_wave_insts_per_ray": v["SQ_INSTS_VALU"] / max(nrays, 1),
+                    "valu_issue_frac_of_2cyc_peak": v.get("valu_issue_frac"), "sclk_ghz_profiled": v.get("sclk_ghz"),
+                    "source": "profiles/r02_pmc_valu.json (same kernel sources); see profiles/r02_valu_issue.md"}
+        result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_packet", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
     if rank == 0 and not a.no_cpu and world == 1:
         try:
             sw, sh = (int(x) for x in a.cpu_sample.split("x"))
             result["cpu_baseline"] = cpu_baseline(a.scene, sw, sh)
         except Exception as e:  # the baseline is a reported number, not a dependency of the measurement
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
+        if result["cpu_baseline"].get("kind") == "port":
+            print("bench.py: oracle/_ref (the compiled reference) is absent: cpu_baseline is the oracle PORT, not the reference",
+                  file=sys.stderr, flush=True)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -126,6 +126,9 @@ typedef struct rt_stats {
     uint64_t prof_packet_any[8];
     /* collect_stats & 1 only: the longest walk of a single ray, in steps (a launch cannot end before its longest ray) */
     uint64_t max_walk_closest, max_walk_any;
+    double ms_packet;           /* packet kernel of the closest-hit queues (collect_stats & 2); ms_closest is the per-lane kernel alone */
+    uint64_t shadow_unoccluded; /* shadow rays that reached their light, i.e. accumulator updates (collect_stats & 1 only) */
+    uint64_t split_items;       /* work items that long shadow walks were split into (0 in most frames) */
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */
@@ -194,6 +197,14 @@ int rt_set_bmp(rt_context *ctx, int32_t slot, int32_t width, int32_t height, int
 /* Flatten check, BVH build (linear array of 64-byte 4-wide nodes), upload.  Must precede rendering; may be repeated. */
 int rt_commit(rt_context *ctx);
 
+/* Where rt_commit spent its time (the reference lumps scene loading into its one timer, main.cpp:541): host BVH build,
+ * the reference's per-mesh candidate order (exact-tie rule), assembly of the 64-byte records, upload. */
+typedef struct rt_commit_stats {
+    uint64_t n_triangles, bvh_nodes;
+    double ms_bvh_build, ms_reference_order, ms_records, ms_upload;
+} rt_commit_stats;
+int rt_get_commit_stats(rt_context *ctx, rt_commit_stats *out);
+
 /* -- the render loop: stands in for main.cpp:607-650 (+ toneMapping :240, Image::setPixel Image.h:91-95) -- */
 
 /* Whole-image render into host buffers (any may be NULL): out_rgb8[h*w*3] row-major as Image::data but bytes,
@@ -234,6 +245,27 @@ int rt_render_tiles_static(rt_context *ctx, const rt_camera *cam, const rt_rende
 int rt_assemble_tiles_device(rt_context *ctx, int32_t width, int32_t height, int32_t world,
                              int64_t tiles_per_rank, const void *d_tiles_rgb8, const void *d_tiles_rgbf,
                              const void *d_tiles_primid, void *d_rgb8, void *d_rgbf, void *d_primid, void *stream);
+
+/* -- one frame over N GPUs of this process: stands where `#pragma omp parallel for` over the 16x16 tiles stood
+ * (main.cpp:607) -- tiles interleaved over the GPUs (tile t -> rank t % N), scene + BVH replicated, one host thread
+ * per GPU, no collective during rendering, ONE exchange at frame end: RCCL point-to-point over xGMI (ncclGroupStart;
+ * ncclRecv x (N-1) on rank 0 / ncclSend on the peers; ncclGroupEnd) into a preallocated [rank][tile][256] buffer,
+ * then the assembly kernel.  RCCL is dlopen'ed by rt_multi_create (single-GPU users never load it).
+ * Usage: rt_multi_create; rt_set_* on rt_multi_context(m, 0) ONLY; rt_multi_commit (BVH built once, uploaded to every
+ * GPU); rt_multi_render per frame.  The same device may be listed more than once (rehearsal of N ranks on one card):
+ * those ranks exchange by device-to-device copies, since RCCL needs one GPU per rank. */
+typedef struct rt_multi rt_multi;
+#define RT_MULTI_REHEARSE_RCCL 1u /* with ONE device: push rank 0's tiles through ncclSend/ncclRecv to itself */
+int rt_multi_create(const int32_t *device_ids, int32_t n, uint32_t flags, rt_multi **out);
+int rt_multi_destroy(rt_multi *m);
+int32_t rt_multi_size(const rt_multi *m);
+const char *rt_multi_transport(const rt_multi *m); /* "rccl", "copy" or "none" (one rank, nothing to exchange) */
+rt_context *rt_multi_context(rt_multi *m, int32_t rank);
+int rt_multi_commit(rt_multi *m);
+/* out_* as rt_render (host buffers, any may be NULL); stats: NULL or rt_multi_size(m) entries, one per rank.
+ * p->tile_rank / tile_world are ignored (set per rank). */
+int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8, float *out_rgbf,
+                    uint32_t *out_primid, rt_stats *stats);
 
 /* -- trace_ray-style API (main.cpp:221-233) for batches of arbitrary rays; used by the parity tests -- */
 

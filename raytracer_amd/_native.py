@@ -59,10 +59,19 @@ class Stats(C.Structure):
         ("bvh_nodes", C.c_uint64), ("bvh_depth", C.c_uint64), ("n_triangles", C.c_uint64),
         ("nodes_visited_any", C.c_uint64), ("tris_tested_any", C.c_uint64), ("bvh_max_stack", C.c_uint64), ("prof_closest", C.c_uint64 * 10), ("prof_any", C.c_uint64 * 10), ("prof_shade", C.c_uint64 * 6), ("prof_packet_closest", C.c_uint64 * 8), ("prof_packet_any", C.c_uint64 * 8),
         ("max_walk_closest", C.c_uint64), ("max_walk_any", C.c_uint64),
+        ("ms_packet", C.c_double), ("shadow_unoccluded", C.c_uint64), ("split_items", C.c_uint64),
     ]
 
     def as_dict(self):
         return {name: (list(getattr(self, name)) if name.startswith("prof_") else getattr(self, name)) for name, _ in self._fields_}
+
+
+class CommitStats(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint64), ("bvh_nodes", C.c_uint64), ("ms_bvh_build", C.c_double),
+                ("ms_reference_order", C.c_double), ("ms_records", C.c_double), ("ms_upload", C.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
 
 
 class Hit(C.Structure):
@@ -72,6 +81,16 @@ class Hit(C.Structure):
         ("normal_shading", C.c_float * 3), ("uv", C.c_float * 2), ("tangent", C.c_float * 3),
         ("bitangent", C.c_float * 3), ("_pad", C.c_float * 2),
     ]
+
+
+def kernel_source_hash():
+    """sha256 over the device-side sources: profiles/*.json carry it so that counter values are only ever attached to
+    measurements of the kernels they were collected on (bench.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rt_kernels.hip", "rt_device.h", "rt_types.h"):
+        h.update(open(os.path.join(PKG_DIR, "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 assert C.sizeof(Material) == 96 and C.sizeof(Hit) == 96 and C.sizeof(Camera) == 96
@@ -108,6 +127,16 @@ def hip_lib():
     lib.rt_render_tiles_device.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, VP, P(Stats)]
     lib.rt_render_tiles_static.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, VP]
     lib.rt_assemble_tiles_device.argtypes = [VP, I32, I32, I32, I64, VP, VP, VP, VP, VP, VP, VP]
+    lib.rt_multi_create.argtypes = [P(I32), I32, C.c_uint32, P(VP)]
+    lib.rt_multi_destroy.argtypes = [VP]
+    lib.rt_multi_size.argtypes = [VP]
+    lib.rt_multi_transport.argtypes = [VP]
+    lib.rt_multi_transport.restype = C.c_char_p
+    lib.rt_multi_context.argtypes = [VP, I32]
+    lib.rt_multi_context.restype = VP
+    lib.rt_multi_commit.argtypes = [VP]
+    lib.rt_multi_render.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, VP]
+    lib.rt_get_commit_stats.argtypes = [VP, P(CommitStats)]
     lib.rt_trace_batch.argtypes = [VP, I64, VP, I32, VP, VP, VP, P(Stats)]
     lib.rt_eval_texture.argtypes = [VP, I32, I64, VP, VP]
     lib.rt_eval_perlin.argtypes = [VP, I64, VP, VP]

@@ -5,13 +5,18 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include "rt_bvh.h"
 #include "rt_kernels.h"
@@ -79,6 +84,8 @@ struct rt_context {
     int bmp_w[4] = {0, 0, 0, 0}, bmp_h[4] = {0, 0, 0, 0}, bmp_c[4] = {0, 0, 0, 0};
     // committed scene
     bool committed = false;
+    rt_commit_stats commit_stats{};
+    struct { uint64_t n_nodes = 0, n_triangles = 0; } info;  // (a replica of rt_multi keeps no triangle arrays / tree of its own)
     RtBvh bvh;
     std::vector<int64_t> mesh_first;  // per object: first global triangle index (or -1)
     DevBuf<RtNode4> d_records;  // BVH nodes, then the triangle records (rt_types.h)
@@ -212,7 +219,7 @@ struct KernelTimer {  // optional per-kernel-class timing with HIP events on the
         if (!on) return;
         (void)hipEventRecord(spans.back().b, stream);
     }
-    void collect(double *ms /*[5]*/) {
+    void collect(double *ms /*[6]*/) {
         for (Span &s : spans) {
             float t = 0;
             (void)hipEventElapsedTime(&t, s.a, s.b);
@@ -229,12 +236,15 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
         st->rays_closest += c[RT_CNT_RAYS(d)];
         st->rays_shadow += c[RT_CNT_SHADOW(d)];
     }
+    auto u64at = [&](int w) { return ((uint64_t)c[w + 1] << 32) | c[w]; };
     st->rays_closest -= c[RT_CNT_INVALID];  // slots of pixels outside the image and unused slab slots are not rays
     st->rays_shadow -= c[RT_CNT_SHADOW_HOLES];
     st->shadow_culled += c[RT_CNT_CULLED];
+    st->shadow_unoccluded += u64at(RT_CNT_UNOCCLUDED);
+    for (int d = 0; d <= max_depth && d < 16; d++)
+        for (int r = 0; r <= RT_SPLIT_ROUNDS; r++) st->split_items += c[RT_CNT_SPLIT(d, r)];
     st->hits_shaded += c[RT_CNT_SHADED];
     st->queue_overflow += c[RT_CNT_OVERFLOW];
-    auto u64at = [&](int w) { return ((uint64_t)c[w + 1] << 32) | c[w]; };
     st->nodes_visited += u64at(RT_CNT_NODES);
     st->tris_tested += u64at(RT_CNT_NODES + 2);
     st->nodes_visited_any += u64at(RT_CNT_ANY_NODES);
@@ -257,8 +267,13 @@ void runLevels(rt_context *ctx, const RtQueues &q, const RtLaunchCfg &cfg, int m
                int stats, KernelTimer &kt, rt_stats *st, uint64_t level0_rays, bool level0_traced = false) {
     for (int level = 0; level <= max_depth; level++) {
         if (!(level == 0 && level0_traced)) {  // each level's queue is claimed once (dynamic fetch counters)
+            if (rtLevelUsesPackets(cfg, level, false)) {
+                kt.begin(5);
+                rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats, 1);
+                kt.end();
+            }
             kt.begin(1);
-            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats);
+            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats, 2);
             kt.end();
         }
         kt.begin(2);
@@ -379,9 +394,10 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     st->ms_total = ms;
-    double cls[5] = {0, 0, 0, 0, 0};
+    double cls[6] = {0, 0, 0, 0, 0, 0};
     kt.collect(cls);
     st->ms_gen = cls[0]; st->ms_closest = cls[1]; st->ms_shade = cls[2]; st->ms_any = cls[3]; st->ms_resolve = cls[4];
+    st->ms_packet = cls[5];
     std::vector<uint32_t> hc(std::max<size_t>(n_chunks, 1) * RT_CNT_WORDS, 0);
     if (n_chunks) HIPOK(hipMemcpy(hc.data(), ctx->d_chunk_counters.p, n_chunks * RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t c = 0; c < n_chunks; c++) addCounters(st, &hc[c * RT_CNT_WORDS], p->max_depth);
@@ -395,10 +411,10 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         }
         st->primary_samples = pix * p->spp;
     }
-    st->bvh_nodes = ctx->bvh.nodes.size();
+    st->bvh_nodes = ctx->info.n_nodes;
     st->bvh_depth = ctx->bvh.depth;
     st->bvh_max_stack = ctx->bvh.max_stack;
-    st->n_triangles = ctx->tri_flags.size();
+    st->n_triangles = ctx->info.n_triangles;
     if (st->queue_overflow) return fail("wavefront queue overflow (" + std::to_string(st->queue_overflow) + " rays dropped)");
     return 0;
 }
@@ -601,9 +617,21 @@ int rt_set_bmp(rt_context *ctx, int32_t slot, int32_t w, int32_t h, int32_t c, c
     return 0;
 }
 
-int rt_commit(rt_context *ctx) {
-    if (!ctx) return fail("rt_commit: NULL context");
-    if (bind(ctx)) return 1;
+namespace {
+double nowMs() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Host half of rt_commit: checks, BVH build, the reference's candidate order, the 64-byte record array.  The result
+// is device independent, so a multi-GPU set-up (rt_multi_commit) builds it once and uploads it to every GPU.
+struct CommitImage {
+    std::vector<RtNode4> records;   // BVH nodes, then one record per triangle in leaf (slot) order
+    std::vector<RtTriShade> shade;
+    std::vector<RtSphere> units;    // spheres, then cones: one device array
+};
+
+int commitHost(rt_context *ctx, CommitImage &img) {
+    const double t0 = nowMs();
     const int n_obj = (int)ctx->object_material.size(), n_mat = (int)ctx->materials.size();
     const int64_t nt = (int64_t)ctx->tri_flags.size();
     for (int m : ctx->object_material)
@@ -617,8 +645,8 @@ int rt_commit(rt_context *ctx) {
             if (!objOk(s.object)) return fail("rt_commit: sphere / cone object_id out of range");
             s.material = ctx->object_material[s.object];
         }
-    std::vector<RtSphere> units = ctx->spheres;  // spheres, then cones: one device array
-    units.insert(units.end(), ctx->cones.begin(), ctx->cones.end());
+    img.units = ctx->spheres;
+    img.units.insert(img.units.end(), ctx->cones.begin(), ctx->cones.end());
     for (RtPlane &p : ctx->planes) {
         if (!objOk(p.object)) return fail("rt_commit: plane object_id out of range");
         p.material = ctx->object_material[p.object];
@@ -634,18 +662,20 @@ int rt_commit(rt_context *ctx) {
 
     // acceleration structure + reordered triangle records
     rtBuildBvh(nt, ctx->v0.data(), ctx->v1.data(), ctx->v2.data(), ctx->bvh);
+    const double t1 = nowMs();
     std::vector<uint32_t> rank((size_t)nt);
     rtReferenceOrder(nt, ctx->v0.data(), ctx->v1.data(), ctx->v2.data(), ctx->tri_object.data(), rank.data());
+    const double t2 = nowMs();
     ctx->mesh_first.assign(n_obj, -1);
     for (int64_t k = nt - 1; k >= 0; k--) ctx->mesh_first[ctx->tri_object[k]] = k;
     // record array: nodes first, then one 64-byte record per triangle in leaf (slot) order
     const size_t nn = ctx->bvh.nodes.size();
     static_assert(sizeof(RtNode4) == 64 && sizeof(RtTriGeom) == 64, "records are 64 bytes");
     if (nn + (size_t)nt >= (1ull << 28)) return fail("rt_commit: more than 2^28 BVH records");
-    std::vector<RtNode4> records(nn + (size_t)nt);
-    if (nn) std::memcpy(records.data(), ctx->bvh.nodes.data(), nn * sizeof(RtNode4));
-    RtTriGeom *geom = reinterpret_cast<RtTriGeom *>(records.data() + nn);
-    std::vector<RtTriShade> shade((size_t)nt);
+    img.records.resize(nn + (size_t)nt);
+    if (nn) std::memcpy(img.records.data(), ctx->bvh.nodes.data(), nn * sizeof(RtNode4));
+    RtTriGeom *geom = reinterpret_cast<RtTriGeom *>(img.records.data() + nn);
+    img.shade.resize((size_t)nt);
     for (int64_t slot = 0; slot < nt; slot++) {
         const size_t t = ctx->bvh.order[slot];
         const float *A = &ctx->v0[3 * t], *B = &ctx->v1[3 * t], *C = &ctx->v2[3 * t];
@@ -662,7 +692,7 @@ int rt_commit(rt_context *ctx) {
         g.rank = rank[t];
         g.prim = (uint32_t)t;
         g._pad = 0;
-        RtTriShade &s = shade[slot];
+        RtTriShade &s = img.shade[slot];
         std::memcpy(s.nA, &ctx->nA[3 * t], 12); std::memcpy(s.nB, &ctx->nB[3 * t], 12); std::memcpy(s.nC, &ctx->nC[3 * t], 12);
         std::memcpy(s.tA, &ctx->tA[2 * t], 8); std::memcpy(s.tB, &ctx->tB[2 * t], 8); std::memcpy(s.tC, &ctx->tC[2 * t], 8);
         s.flags = ctx->tri_flags[t];
@@ -671,21 +701,51 @@ int rt_commit(rt_context *ctx) {
         s.rank = rank[t];
         s.material = ctx->object_material[(size_t)ctx->tri_object[t]];
     }
-    if (ctx->d_records.upload(records) || ctx->d_shade.upload(shade) || ctx->d_nodes_p.upload(ctx->bvh.nodes_p)) return 1;
-    if (ctx->d_spheres.upload(units) || ctx->d_planes.upload(ctx->planes)) return 1;
-    if (ctx->d_materials.upload(ctx->materials) || ctx->d_objmat.upload(ctx->object_material) || ctx->d_lights.upload(ctx->lights)) return 1;
+    const double t3 = nowMs();
+    ctx->commit_stats = rt_commit_stats{};
+    ctx->commit_stats.n_triangles = (uint64_t)nt;
+    ctx->commit_stats.bvh_nodes = nn;
+    ctx->commit_stats.ms_bvh_build = t1 - t0;
+    ctx->commit_stats.ms_reference_order = t2 - t1;
+    ctx->commit_stats.ms_records = t3 - t2;
+    return 0;
+}
+
+// Device half of rt_commit: uploads `img` (built from `src`'s host-side scene; src == ctx for a single GPU) to ctx's GPU
+int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img) {
+    const double t0 = nowMs();
+    if (bind(ctx)) return 1;
+    if (ctx != src) {  // replica: the small host-side tables the render paths read
+        ctx->materials = src->materials;
+        ctx->object_material = src->object_material;
+        ctx->planes = src->planes;
+        ctx->lights = src->lights;
+        std::memcpy(ctx->ambient, src->ambient, sizeof ctx->ambient);
+        ctx->mesh_first = src->mesh_first;
+        ctx->bvh = RtBvh{};
+        ctx->bvh.root_ref = src->bvh.root_ref; ctx->bvh.depth = src->bvh.depth; ctx->bvh.max_stack = src->bvh.max_stack;
+        ctx->bvh.bound = src->bvh.bound;
+        ctx->commit_stats = src->commit_stats;
+    }
+    const size_t nn = src->bvh.nodes.size();
+    const int64_t nt = (int64_t)src->tri_flags.size();
+    ctx->info.n_nodes = nn;
+    ctx->info.n_triangles = (uint64_t)nt;
+    if (ctx->d_records.upload(img.records) || ctx->d_shade.upload(img.shade) || ctx->d_nodes_p.upload(src->bvh.nodes_p)) return 1;
+    if (ctx->d_spheres.upload(img.units) || ctx->d_planes.upload(src->planes)) return 1;
+    if (ctx->d_materials.upload(src->materials) || ctx->d_objmat.upload(src->object_material) || ctx->d_lights.upload(src->lights)) return 1;
     RtSceneDev &d = ctx->dev;
     std::memset(&d, 0, sizeof d);
     for (int k = 0; k < 4; k++) {
-        if (ctx->bmp_w[k]) {
-            if (ctx->d_bmp[k].upload(ctx->bmp[k])) return 1;
+        if (src->bmp_w[k]) {
+            if (ctx->d_bmp[k].upload(src->bmp[k])) return 1;
             d.bmp[k] = ctx->d_bmp[k].p;
         }
-        d.bmp_w[k] = ctx->bmp_w[k]; d.bmp_h[k] = ctx->bmp_h[k]; d.bmp_c[k] = ctx->bmp_c[k];
+        d.bmp_w[k] = src->bmp_w[k]; d.bmp_h[k] = src->bmp_h[k]; d.bmp_c[k] = src->bmp_c[k];
     }
     d.nodes = ctx->d_records.p;
     d.tri_geom = reinterpret_cast<const RtTriGeom *>(ctx->d_records.p + nn);
-    d.bound = ctx->bvh.bound;
+    d.bound = src->bvh.bound;
     d.nodes_p = ctx->d_nodes_p.p;
     d.tri_shade = ctx->d_shade.p;
     d.spheres = ctx->d_spheres.p;
@@ -693,19 +753,19 @@ int rt_commit(rt_context *ctx) {
     d.materials = ctx->d_materials.p;
     d.object_material = ctx->d_objmat.p;
     d.lights = ctx->d_lights.p;
-    std::memcpy(d.ambient, ctx->ambient, 12);
-    d.n_nodes = (int)ctx->bvh.nodes.size();
+    std::memcpy(d.ambient, src->ambient, 12);
+    d.n_nodes = (int)nn;
     d.n_tris = (int)nt;
-    d.n_spheres = (int)units.size();
-    d.n_planes = (int)ctx->planes.size();
-    d.n_lights = (int)ctx->lights.size();
-    d.n_objects = n_obj;
-    d.n_materials = n_mat;
+    d.n_spheres = (int)img.units.size();
+    d.n_planes = (int)src->planes.size();
+    d.n_lights = (int)src->lights.size();
+    d.n_objects = (int)src->object_material.size();
+    d.n_materials = (int)src->materials.size();
     // traversal stack: up to RT_LDS_STACK rows per lane in LDS (16 KB per 256-thread block), the rest of the worst case
     // (sum of children - 1 along the deepest path; rarely reached) in a global spill area per grid thread
-    const int entries = std::max(1, std::min(ctx->bvh.max_stack, RT_LDS_STACK));
+    const int entries = std::max(1, std::min(src->bvh.max_stack, RT_LDS_STACK));
     ctx->cfg.stack_entries = entries;
-    ctx->cfg.packets = nn > 0 && ctx->bvh.max_stack <= 64;  // the packet walk keeps its stack in one VGPR (64 lanes)
+    ctx->cfg.packets = nn > 0 && src->bvh.max_stack <= 64;  // the packet walk keeps its stack in one VGPR (64 lanes)
     if (const char *e = getenv("RT_PACKET_LEVELS")) {  // tuning knob: "<closest levels>,<shadow levels>"
         int a = 1, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2) { ctx->cfg.packet_levels_closest = a; ctx->cfg.packet_levels_any = b; }
@@ -714,7 +774,7 @@ int rt_commit(rt_context *ctx) {
     if (const char *e = getenv("RT_ANY_ORDERED")) ctx->dev.any_ordered = atoi(e) != 0;
     ctx->dev.occluder_cache = 1;  // RT_OCCLUDER_CACHE=0: shadow queries independent of scheduling down to the last float bit
     if (const char *e = getenv("RT_OCCLUDER_CACHE")) ctx->dev.occluder_cache = atoi(e) != 0;
-    ctx->cfg.analytic_bytes = (int)(units.size() * sizeof(RtSphere) + ctx->planes.size() * sizeof(RtPlane));
+    ctx->cfg.analytic_bytes = (int)(img.units.size() * sizeof(RtSphere) + src->planes.size() * sizeof(RtPlane));
     const int lds_per_block = (entries + 1) * 256 * 4 + ctx->cfg.analytic_bytes;  // stack rows + the age row + analytic primitives
     if (const char *e = getenv("RT_SPLIT_BUDGET")) {  // 0 = never split a shadow walk; rounded down to a power of two
         int b = std::max(0, atoi(e)), p2 = 0;
@@ -722,10 +782,28 @@ int rt_commit(rt_context *ctx) {
         ctx->cfg.split_budget = atoi(e) > 0 ? 1 << p2 : 0;
     }
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
-    const size_t spill_entries = (size_t)std::max(0, ctx->bvh.max_stack - entries);
+    const size_t spill_entries = (size_t)std::max(0, src->bvh.max_stack - entries);
     if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;
     ctx->q.spill = ctx->d_spill.p;
+    HIPOK(hipDeviceSynchronize());
+    ctx->commit_stats.ms_upload = nowMs() - t0;
     ctx->committed = true;
+    return 0;
+}
+}  // namespace
+
+int rt_commit(rt_context *ctx) {
+    if (!ctx) return fail("rt_commit: NULL context");
+    ctx->committed = false;
+    CommitImage img;
+    if (commitHost(ctx, img)) return 1;
+    return commitDevice(ctx, ctx, img);
+}
+
+int rt_get_commit_stats(rt_context *ctx, rt_commit_stats *out) {
+    if (!ctx || !out) return fail("rt_get_commit_stats: NULL argument");
+    if (!ctx->committed) return fail("rt_get_commit_stats: no committed scene");
+    *out = ctx->commit_stats;
     return 0;
 }
 
@@ -1051,6 +1129,241 @@ int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_trian
     if (n_triangles) *n_triangles = (int64_t)ctx->bvh.order.size();
     if (nodes && !ctx->bvh.nodes.empty()) std::memcpy(nodes, ctx->bvh.nodes.data(), ctx->bvh.nodes.size() * sizeof(RtNode4));
     if (tri_order && !ctx->bvh.order.empty()) std::memcpy(tri_order, ctx->bvh.order.data(), ctx->bvh.order.size() * sizeof(uint32_t));
+    return 0;
+}
+
+
+// ---- rt_multi: one frame over N GPUs of this process ------------------------------------------------------------------
+// Stands where `#pragma omp parallel for schedule(dynamic, 1)` over the 16x16 tiles stood (main.cpp:607): the tiles are
+// interleaved over the GPUs (tile t -> rank t % N), scene + BVH are replicated (built once on the host, uploaded N times),
+// every GPU renders its tiles from a host thread of its own, and ONE exchange step assembles the frame on rank 0:
+// RCCL point-to-point over xGMI -- ncclGroupStart; ncclRecv x (N-1) on rank 0 / ncclSend on the peers; ncclGroupEnd --
+// straight into the slots of a preallocated [rank][tile][256] buffer (rank 0 renders into its own slot), then
+// k_assemble de-interleaves.  No collective during rendering.  RCCL (573 MB of code objects) is loaded with dlopen when
+// the first rt_multi is created, so single-GPU users of the library never map it.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+};
+RcclApi g_rccl;
+int loadRccl() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (g_rccl.lib) return 0;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(std::string("rt_multi: cannot load RCCL: ") + dlerror());
+    RcclApi a;
+    a.lib = lib;
+#define RT_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(lib, name)); if (!a.field) return fail(std::string("rt_multi: RCCL lacks ") + name)
+    RT_SYM(commInitAll, "ncclCommInitAll");
+    RT_SYM(commDestroy, "ncclCommDestroy");
+    RT_SYM(groupStart, "ncclGroupStart");
+    RT_SYM(groupEnd, "ncclGroupEnd");
+    RT_SYM(send, "ncclSend");
+    RT_SYM(recv, "ncclRecv");
+    RT_SYM(errorString, "ncclGetErrorString");
+#undef RT_SYM
+    g_rccl = a;
+    return 0;
+}
+#define NCCLOK(expr)                                                                                   \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess) return fail(std::string(#expr) + ": " + g_rccl.errorString(r_));       \
+    } while (0)
+}  // namespace
+
+struct rt_multi {
+    int n = 0;
+    std::vector<int> dev;
+    std::vector<rt_context *> ctx;
+    bool rccl = false;       // transport of the frame-end exchange: RCCL send/recv, else device-to-device copies
+    bool self_rccl = false;  // n == 1: push rank 0's own tiles through ncclSend/ncclRecv to itself (rehearsal on a 1-GPU box)
+    std::vector<ncclComm_t> comms;
+    int64_t per = 0;         // tiles per rank the buffers below are sized for
+    // rank-local tile-major buffers of ranks >= 1 (and of rank 0 under self_rccl), each on its rank's GPU
+    std::vector<DevBuf<uint8_t>> t8;
+    std::vector<DevBuf<float>> tf;
+    std::vector<DevBuf<uint32_t>> tp;
+    // on rank 0's GPU: the gathered buffers [rank][per][256][..] and the assembled row-major images
+    DevBuf<uint8_t> g8, o8;
+    DevBuf<float> gf, of;
+    DevBuf<uint32_t> gp, op;
+};
+
+int rt_multi_create(const int32_t *device_ids, int32_t n, uint32_t flags, rt_multi **out) {
+    if (!out) return fail("rt_multi_create: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n <= 0 || n > 64) return fail("rt_multi_create: bad arguments (1..64 devices)");
+    rt_multi *m = new rt_multi();
+    m->n = n;
+    m->dev.assign(device_ids, device_ids + n);
+    m->t8.resize(n); m->tf.resize(n); m->tp.resize(n);
+    bool distinct = true;
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++)
+            if (device_ids[a] == device_ids[b]) distinct = false;
+    for (int k = 0; k < n; k++) {
+        rt_context *c = nullptr;
+        if (rt_create(device_ids[k], &c)) {
+            for (rt_context *x : m->ctx) rt_destroy(x);
+            delete m;
+            return 1;
+        }
+        m->ctx.push_back(c);
+    }
+    const char *tr = getenv("RT_MULTI_TRANSPORT");  // "copy": device-to-device copies instead of RCCL
+    const bool want_copy = tr && std::string(tr) == "copy";
+    m->self_rccl = n == 1 && (flags & RT_MULTI_REHEARSE_RCCL) != 0;
+    // RCCL needs one GPU per rank: ranks that share a GPU (a rehearsal of N ranks on one card) exchange by copies
+    m->rccl = !want_copy && distinct && (n > 1 || m->self_rccl);
+    if (m->rccl) {
+        if (loadRccl()) { rt_multi_destroy(m); return 1; }
+        m->comms.assign(n, nullptr);
+        ncclResult_t r = g_rccl.commInitAll(m->comms.data(), n, m->dev.data());
+        if (r != ncclSuccess) {
+            m->comms.clear();
+            rt_multi_destroy(m);
+            return fail(std::string("rt_multi_create: ncclCommInitAll: ") + g_rccl.errorString(r));
+        }
+    }
+    *out = m;
+    return 0;
+}
+
+int rt_multi_destroy(rt_multi *m) {
+    if (!m) return 0;
+    for (int k = 0; k < m->n && k < (int)m->ctx.size(); k++) {
+        (void)hipSetDevice(m->dev[k]);
+        (void)hipDeviceSynchronize();
+        m->t8[k].release(); m->tf[k].release(); m->tp[k].release();
+    }
+    for (ncclComm_t c : m->comms)
+        if (c) (void)g_rccl.commDestroy(c);
+    if (!m->ctx.empty()) {
+        (void)hipSetDevice(m->dev[0]);
+        m->g8.release(); m->gf.release(); m->gp.release(); m->o8.release(); m->of.release(); m->op.release();
+    }
+    for (rt_context *c : m->ctx) rt_destroy(c);
+    delete m;
+    return 0;
+}
+
+int32_t rt_multi_size(const rt_multi *m) { return m ? m->n : 0; }
+const char *rt_multi_transport(const rt_multi *m) { return !m ? "" : m->rccl ? "rccl" : (m->n > 1 ? "copy" : "none"); }
+
+rt_context *rt_multi_context(rt_multi *m, int32_t rank) {
+    if (!m || rank < 0 || rank >= m->n) return nullptr;
+    return m->ctx[rank];
+}
+
+int rt_multi_commit(rt_multi *m) {
+    if (!m) return fail("rt_multi_commit: NULL argument");
+    rt_context *src = m->ctx[0];
+    for (rt_context *c : m->ctx) c->committed = false;
+    CommitImage img;
+    if (commitHost(src, img)) return 1;
+    // uploads run concurrently, one host thread per GPU
+    std::vector<int> rc(m->n, 0);
+    std::vector<std::string> err(m->n);
+    std::vector<std::thread> th;
+    for (int k = 0; k < m->n; k++)
+        th.emplace_back([&, k] {
+            rc[k] = commitDevice(m->ctx[k], src, img);
+            if (rc[k]) err[k] = g_err;
+        });
+    for (std::thread &t : th) t.join();
+    for (int k = 0; k < m->n; k++)
+        if (rc[k]) return fail("rt_multi_commit: rank " + std::to_string(k) + ": " + err[k]);
+    return 0;
+}
+
+int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8, float *out_rgbf,
+                    uint32_t *out_primid, rt_stats *stats) {
+    if (!m || !cam || !p) return fail("rt_multi_render: NULL argument");
+    if (p->width <= 0 || p->height <= 0) return fail("rt_multi_render: bad image size");
+    const int n = m->n;
+    int64_t per = 0;
+    rt_tile_counts(p->width, p->height, 0, n, &per, nullptr);  // rank 0 owns the most tiles: every slot has that size
+    const size_t slot = (size_t)per * RT_TILE_PIXELS, npix = (size_t)p->width * p->height;
+    const bool want_f = out_rgbf != nullptr;
+    // buffers (kept across frames): gathered + assembled on rank 0's GPU, tile buffers on the peers' GPUs
+    HIPOK(hipSetDevice(m->dev[0]));
+    if (m->g8.alloc(slot * 3 * n) || m->gp.alloc(slot * n) || m->o8.alloc(npix * 3) || m->op.alloc(npix)) return 1;
+    if (want_f && (m->gf.alloc(slot * 3 * n) || m->of.alloc(npix * 3))) return 1;
+    for (int k = (m->self_rccl ? 0 : 1); k < n; k++) {
+        HIPOK(hipSetDevice(m->dev[k]));
+        if (m->t8[k].alloc(slot * 3) || m->tp[k].alloc(slot) || (want_f && m->tf[k].alloc(slot * 3))) return 1;
+    }
+    m->per = per;
+    // ---- render: one host thread per GPU, each rank its interleaved tiles ----
+    std::vector<int> rc(n, 0);
+    std::vector<std::string> err(n);
+    std::vector<rt_stats> st(n);
+    auto local8 = [&](int k) { return (k == 0 && !m->self_rccl) ? m->g8.p : m->t8[k].p; };  // rank 0 renders into its slot
+    auto localf = [&](int k) { return !want_f ? nullptr : (k == 0 && !m->self_rccl) ? m->gf.p : m->tf[k].p; };
+    auto localp = [&](int k) { return (k == 0 && !m->self_rccl) ? m->gp.p : m->tp[k].p; };
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < n; k++)
+            th.emplace_back([&, k] {
+                rt_render_params q = *p;
+                q.tile_rank = k;
+                q.tile_world = n;
+                rc[k] = renderTiles(m->ctx[k], cam, &q, local8(k), localf(k), localp(k), m->ctx[k]->stream, &st[k]);
+                if (rc[k]) err[k] = g_err;
+            });
+        for (std::thread &t : th) t.join();
+    }
+    for (int k = 0; k < n; k++)
+        if (rc[k]) return fail("rt_multi_render: rank " + std::to_string(k) + ": " + err[k]);
+    // ---- the one exchange step ----
+    hipStream_t s0 = m->ctx[0]->stream;
+    const int first = m->self_rccl ? 0 : 1;
+    if (m->rccl) {
+        NCCLOK(g_rccl.groupStart());
+        for (int k = first; k < n; k++) {
+            NCCLOK(g_rccl.recv(m->g8.p + (size_t)k * slot * 3, slot * 3, ncclUint8, k, m->comms[0], s0));
+            NCCLOK(g_rccl.recv(m->gp.p + (size_t)k * slot, slot, ncclUint32, k, m->comms[0], s0));
+            if (want_f) NCCLOK(g_rccl.recv(m->gf.p + (size_t)k * slot * 3, slot * 3, ncclFloat32, k, m->comms[0], s0));
+            hipStream_t sk = m->ctx[k]->stream;
+            NCCLOK(g_rccl.send(m->t8[k].p, slot * 3, ncclUint8, 0, m->comms[k], sk));
+            NCCLOK(g_rccl.send(m->tp[k].p, slot, ncclUint32, 0, m->comms[k], sk));
+            if (want_f) NCCLOK(g_rccl.send(m->tf[k].p, slot * 3, ncclFloat32, 0, m->comms[k], sk));
+        }
+        NCCLOK(g_rccl.groupEnd());
+        for (int k = first; k < n; k++) {  // the peers' sends have left their buffers (next frame may overwrite them)
+            if (k == 0) continue;
+            HIPOK(hipSetDevice(m->dev[k]));
+            HIPOK(hipStreamSynchronize(m->ctx[k]->stream));
+        }
+    } else {
+        for (int k = first; k < n; k++) {  // ranks that share a GPU (rehearsal) or RT_MULTI_TRANSPORT=copy
+            HIPOK(hipSetDevice(m->dev[0]));
+            HIPOK(hipMemcpyPeerAsync(m->g8.p + (size_t)k * slot * 3, m->dev[0], m->t8[k].p, m->dev[k], slot * 3, s0));
+            HIPOK(hipMemcpyPeerAsync(m->gp.p + (size_t)k * slot, m->dev[0], m->tp[k].p, m->dev[k], slot * sizeof(uint32_t), s0));
+            if (want_f) HIPOK(hipMemcpyPeerAsync(m->gf.p + (size_t)k * slot * 3, m->dev[0], m->tf[k].p, m->dev[k], slot * 3 * sizeof(float), s0));
+        }
+    }
+    // ---- rank 0: de-interleave (stream-ordered behind the receives), hand the image to the host ----
+    HIPOK(hipSetDevice(m->dev[0]));
+    if (rt_assemble_tiles_device(m->ctx[0], p->width, p->height, n, per, m->g8.p, want_f ? m->gf.p : nullptr, m->gp.p, m->o8.p,
+                                 want_f ? m->of.p : nullptr, m->op.p, s0))
+        return 1;
+    if (out_rgb8) HIPOK(hipMemcpy(out_rgb8, m->o8.p, npix * 3, hipMemcpyDeviceToHost));
+    if (out_rgbf) HIPOK(hipMemcpy(out_rgbf, m->of.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_primid) HIPOK(hipMemcpy(out_primid, m->op.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (stats)
+        for (int k = 0; k < n; k++) stats[k] = st[k];
     return 0;
 }
 

@@ -21,8 +21,13 @@ struct RtLaunchCfg {
 };
 
 void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles);
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats);  // stats: 0 plain, 1 counters, 2 + wave-time profile
-void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats);
+// stats: 0 plain, 1 counters, 2 + wave-time profile; part: 0 = packet kernel (if the level has one) + per-lane kernels,
+// 1 = packet kernel only, 2 = per-lane kernels only (separate timing)
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part = 0);
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part = 0);
+inline bool rtLevelUsesPackets(const RtLaunchCfg &cfg, int level, bool any) {
+    return cfg.packets && level < (any ? cfg.packet_levels_any : cfg.packet_levels_closest);
+}
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs);
 // waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)

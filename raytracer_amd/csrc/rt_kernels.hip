@@ -514,6 +514,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     // conversions and atomics) would run once per ray with one or two lanes active.
     bool fin = false;
     uint32_t walk = 0;  // STATS: steps of the lane's current ray (the longest walk bounds a launch's tail)
+    uint32_t unocc = 0; // STATS: shadow rays of this lane that reached their light
     // Occluder cache (any-hit queue pass): "occluded" only asks whether ANY triangle lies in front of the light, so the
     // order of the tests is free.  Neighbouring shadow rays (a slab holds rays from neighbouring hits towards one light)
     // are mostly blocked by the same triangle: a new ray starts with the last occluder found in this wave as its
@@ -538,6 +539,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             add = !occl && old == 1u;  // (old carries the flag if any earlier item set it)
             occl = false;
         }
+        if (COUNT && ANY && add) unocc++;
         if (ANY && add) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
@@ -757,6 +759,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     if (COUNT) {
         if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
+        if (ANY) {
+            unsigned long long u = unocc;
+            for (int off = 32; off > 0; off >>= 1) u += __shfl_down(u, off);
+            if (laneId() == 0 && u) atomicAdd(reinterpret_cast<unsigned long long *>(q.counters + RT_CNT_UNOCCLUDED), u);
+        }
         if (PROF) prof[7] = __builtin_amdgcn_s_memtime() - tStart;
         if (laneId() == 0) {  // counts of phases / lanes / refills / rays with COUNT, their clocks with PROF
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + (ANY ? RT_CNT_PROF_ANY : RT_CNT_PROF_CLOSEST));
@@ -1495,8 +1502,10 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
     hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles);
 }
 // packets first (when the tree allows a wave-level stack), then the per-lane kernel over what they handed back
+// part: 0 = everything, 1 = only the packet kernel (if the level has one), 2 = only the per-lane kernels (so that the
+// caller can time the two separately)
 template <bool ANY>
-static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats) {
+static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part) {
     const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
     const uint32_t budget = ANY && q.split_cap ? (uint32_t)cfg.split_budget : 0u;
@@ -1510,10 +1519,12 @@ static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t r
 #define RT_A_QUEUE(S) RT_LAUNCHA(S, RT_MODE_QUEUE, grid, -1, budget)
 #define RT_C_RESID(S) RT_LAUNCHC(S, RT_MODE_RESID)
 #define RT_C_QUEUE(S) RT_LAUNCHC(S, RT_MODE_QUEUE)
-    if (cfg.packets && level < (ANY ? cfg.packet_levels_any : cfg.packet_levels_closest)) {
-        RT_BY_STATS(RT_PK);
+    if (rtLevelUsesPackets(cfg, level, ANY)) {
+        if (part != 2) RT_BY_STATS(RT_PK);
+        if (part == 1) return;
         if (ANY) RT_BY_STATS(RT_A_RESID); else RT_BY_STATS(RT_C_RESID);
     } else {
+        if (part == 1) return;
         if (ANY) RT_BY_STATS(RT_A_QUEUE); else RT_BY_STATS(RT_C_QUEUE);
     }
     if (ANY && budget) {
@@ -1538,11 +1549,11 @@ static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t r
 #undef RT_LAUNCHA
 #undef RT_LAUNCHP
 }
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats) {
-    launchTrace<false>(cfg, sc, root_ref, q, level, stats);
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part) {
+    launchTrace<false>(cfg, sc, root_ref, q, level, stats, part);
 }
-void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats) {
-    launchTrace<true>(cfg, sc, root_ref, q, level, stats);
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part) {
+    launchTrace<true>(cfg, sc, root_ref, q, level, stats, part);
 }
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs) {

@@ -1,6 +1,7 @@
 // Scene.cpp -- flattening of the object list and the host side of render()/trace_ray().  See Scene.h.
 #include "Scene.h"
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -137,7 +138,7 @@ FlatScene flattenScene(const std::vector<Object *> &objs, const std::vector<Ligh
     return s;
 }
 
-void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir) {
+void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir, bool commit) {
     rtCheck(rt_set_materials(ctx, (int32_t)s.materials.size(), s.materials.data()), "rt_set_materials");
     rtCheck(rt_set_object_materials(ctx, (int32_t)s.object_material.size(), s.object_material.data()), "rt_set_object_materials");
     rtCheck(rt_set_triangles(ctx, s.triangleCount(), s.v0.data(), s.v1.data(), s.v2.data(), s.nA.data(), s.nB.data(),
@@ -154,7 +155,7 @@ void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture
             rtCheck(rt_set_bmp(ctx, slot, img.width, img.height, img.channels, img.pixels.data()), "rt_set_bmp");
         }
     }
-    rtCheck(rt_commit(ctx), "rt_commit");
+    if (commit) rtCheck(rt_commit(ctx), "rt_commit");
 }
 
 rt_context *defaultContext() {
@@ -233,18 +234,39 @@ static uint64_t sceneFingerprint(const std::string &texture_dir) {
 }
 void invalidateScene() { g_uploaded = false; }
 void setTextureDir(const std::string &dir) { g_texture_dir = dir; }
+// the renderer behind render()/trace_ray(): one context, or -- RenderOptions::devices with more than one entry -- an
+// rt_multi over those GPUs (its rank 0 context also serves trace_ray() and the texture functions)
+static rt_multi *g_multi = nullptr;
+static std::vector<int> g_multi_devices;
+static rt_context *rendererContext(const std::vector<int> &devices) {
+    if (devices.size() <= 1 && !g_multi) {
+        if (devices.size() == 1 && !std::getenv("RT_DEVICE")) setenv("RT_DEVICE", std::to_string(devices[0]).c_str(), 0);
+        return defaultContext();
+    }
+    if (devices.size() > 1 && (!g_multi || devices != g_multi_devices)) {
+        if (g_multi) rt_multi_destroy(g_multi);
+        g_multi = nullptr;
+        std::vector<int32_t> ids(devices.begin(), devices.end());
+        rtCheck(rt_multi_create(ids.data(), (int32_t)ids.size(), 0, &g_multi), "rt_multi_create");
+        g_multi_devices = devices;
+        g_uploaded = false;
+    }
+    return rt_multi_context(g_multi, 0);
+}
 static void ensureUploaded(rt_context *ctx, const std::string &texture_dir) {
     const uint64_t print = sceneFingerprint(texture_dir);
     if (g_uploaded && print == g_uploaded_print) return;
     FlatScene s = flattenScene(objects, lights, ambient_light);
-    uploadScene(ctx, s, texture_dir);
+    const bool multi = g_multi && ctx == rt_multi_context(g_multi, 0);
+    uploadScene(ctx, s, texture_dir, !multi);
+    if (multi) rtCheck(rt_multi_commit(g_multi), "rt_multi_commit");  // BVH built once, uploaded to every GPU
     rt_set_host_texture_context(ctx);
     g_uploaded_print = print;
     g_uploaded = true;
 }
 
 rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
-    rt_context *ctx = defaultContext();
+    rt_context *ctx = rendererContext(opt.devices);
     g_texture_dir = opt.textureDir;  // trace_ray()/trace_rays() after a render() read the same maps
     ensureUploaded(ctx, opt.textureDir);
     rt_render_params p{};
@@ -259,13 +281,25 @@ rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
     rt_camera cam = camera.toC();
     std::vector<uint8_t> rgb8((size_t)3 * p.width * p.height);
     rt_stats st{};
-    rtCheck(rt_render(ctx, &cam, &p, rgb8.data(), nullptr, nullptr, &st), "rt_render");
+    if (g_multi && ctx == rt_multi_context(g_multi, 0)) {
+        // N GPUs: interleaved tiles, one RCCL exchange at frame end (include/rt_hip.h: rt_multi_render)
+        std::vector<rt_stats> per(rt_multi_size(g_multi));
+        rtCheck(rt_multi_render(g_multi, &cam, &p, rgb8.data(), nullptr, nullptr, per.data()), "rt_multi_render");
+        st = per[0];
+        for (size_t k = 1; k < per.size(); k++) {  // counts add up over the ranks, the frame takes as long as the slowest
+            st.primary_samples += per[k].primary_samples; st.rays_closest += per[k].rays_closest; st.rays_shadow += per[k].rays_shadow;
+            st.shadow_culled += per[k].shadow_culled; st.hits_shaded += per[k].hits_shaded; st.queue_overflow += per[k].queue_overflow;
+            st.ms_total = std::max(st.ms_total, per[k].ms_total);
+        }
+    } else {
+        rtCheck(rt_render(ctx, &cam, &p, rgb8.data(), nullptr, nullptr, &st), "rt_render");
+    }
     image.setAll(rgb8.data());
     return st;
 }
 
 std::vector<glm::vec3> trace_rays(const std::vector<Ray> &rays, int bounces, std::vector<Hit> *hits) {
-    rt_context *ctx = defaultContext();
+    rt_context *ctx = g_multi ? rt_multi_context(g_multi, 0) : defaultContext();
     ensureUploaded(ctx, g_texture_dir);  // the directory of the last render(), or setTextureDir(); default ./textures
     const size_t n = rays.size();
     std::vector<float> in(6 * n), col(3 * n);

@@ -68,7 +68,7 @@ struct FlatScene {
 FlatScene flattenScene(const std::vector<Object *> &objs, const std::vector<Light *> &ls, glm::vec3 ambient);
 
 // Uploads a flattened scene (+ the four BMP maps from `texture_dir` when a material needs them) and commits.
-void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir);
+void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir, bool commit = true);
 
 // Lazily created process-wide context on HIP device `device` (default: RT_DEVICE env or 0).
 rt_context *defaultContext();
@@ -79,6 +79,9 @@ struct RenderOptions {
     uint32_t seed = 0;
     int jitterMode = RT_JITTER_AUTO;
     std::string textureDir = "./textures";
+    // HIP devices to render on.  Empty or one entry: one GPU (RT_DEVICE or 0).  More: the frame's tiles are interleaved
+    // over these GPUs and gathered with RCCL (rt_multi_render) -- what `#pragma omp parallel for` was at main.cpp:607.
+    std::vector<int> devices;
 };
 
 // Stands where main.cpp:607-650 stood: renders the global scene into `image` on the GPU.

@@ -4,7 +4,7 @@
 // :625, bounce depth :643) are run-time arguments:
 //
 //   raytracer_hip [--scene sample|bunny|competition|cones] [--width W] [--height H] [--spp N] [--depth D]
-//                 [--assets DIR] [--p3] [output.ppm]
+//                 [--assets DIR] [--p3] [--gpus N] [output.ppm]
 //
 // Output: binary P6 by default (an 8K frame as ASCII P3 is ~400 MB), the reference's ASCII P3 with --p3.
 #include <chrono>
@@ -20,6 +20,7 @@ int main(int argc, const char *argv[]) {
     std::string scene = "competition", assets = ".", out = "./result.ppm";
     int width = 1024, height = 768, spp = 4, depth = 3;  // main.cpp:543-545,625,643
     bool p3 = false;
+    int gpus = 1;  // --gpus N: tiles interleaved over HIP devices 0..N-1, RCCL gather at frame end
     for (int k = 1; k < argc; k++) {
         const std::string a = argv[k];
         auto next = [&](const char *what) -> const char * {
@@ -36,6 +37,7 @@ int main(int argc, const char *argv[]) {
         else if (a == "--depth") depth = std::atoi(next("--depth"));
         else if (a == "--assets") assets = next("--assets");
         else if (a == "--p3") p3 = true;
+        else if (a == "--gpus") gpus = std::atoi(next("--gpus"));
         else if (a.rfind("--", 0) == 0) {
             std::fprintf(stderr, "unknown option %s\n", a.c_str());
             return 2;
@@ -55,6 +57,7 @@ int main(int argc, const char *argv[]) {
         opt.spp = spp;
         opt.maxDepth = depth;
         opt.textureDir = assets + "/textures";
+        for (int g = 0; g < gpus && gpus > 1; g++) opt.devices.push_back(g);
         const auto t1 = std::chrono::steady_clock::now();
         const rt_stats st = render(image, cam, opt);
         const auto t2 = std::chrono::steady_clock::now();

@@ -22,10 +22,14 @@ class RtError(RuntimeError):
 
 
 class Renderer:
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed_ctx=None):
         self.lib = N.hip_lib()
         self._ctx = C.c_void_p()
-        self._check(self.lib.rt_create(int(device), C.byref(self._ctx)))
+        self._owns = _borrowed_ctx is None
+        if _borrowed_ctx is None:
+            self._check(self.lib.rt_create(int(device), C.byref(self._ctx)))
+        else:
+            self._ctx = C.c_void_p(_borrowed_ctx)  # a rank of an rt_multi: destroyed with it
         self.device = int(device)
         self.scene = None
 
@@ -35,8 +39,15 @@ class Renderer:
 
     def close(self):
         if getattr(self, "_ctx", None):
-            self.lib.rt_destroy(self._ctx)
+            if self._owns:
+                self.lib.rt_destroy(self._ctx)
             self._ctx = None
+
+    def commit_stats(self):
+        """where rt_commit spent its time: dict(n_triangles, bvh_nodes, ms_bvh_build, ms_reference_order, ms_records, ms_upload)"""
+        st = N.CommitStats()
+        self._check(self.lib.rt_get_commit_stats(self._ctx, C.byref(st)))
+        return st.as_dict()
 
     def __del__(self):
         try:
@@ -45,7 +56,7 @@ class Renderer:
             pass
 
     # ---- scene ---------------------------------------------------------------------------------------
-    def set_scene(self, s: FlatScene):
+    def set_scene(self, s: FlatScene, commit=True):
         L, ctx = self.lib, self._ctx
         c = np.ascontiguousarray
         mats = c(s.materials)
@@ -61,7 +72,8 @@ class Renderer:
             if b is not None:
                 b = c(b)
                 self._check(L.rt_set_bmp(ctx, slot, b.shape[1], b.shape[0], b.shape[2], _p(b)))
-        self._check(L.rt_commit(ctx))
+        if commit:
+            self._check(L.rt_commit(ctx))
         self.scene = s
         return self
 
@@ -158,3 +170,54 @@ def _trace_batch(self, rays, depth=3, want_hits=True, want_shadow=True):
 
 
 Renderer.trace_batch = _trace_batch
+
+
+class MultiRenderer:
+    """One frame over N GPUs of this process through the C ABI's rt_multi (include/rt_hip.h): interleaved tiles, one host
+    thread per GPU inside the library, RCCL send/recv gather at frame end.  `devices` may repeat a device (a rehearsal of
+    N ranks on one card: those exchange by device copies); rehearse_rccl pushes a single rank's tiles through RCCL."""
+
+    def __init__(self, devices, rehearse_rccl=False):
+        self.lib = N.hip_lib()
+        self._m = C.c_void_p()
+        ids = (C.c_int32 * len(devices))(*devices)
+        if self.lib.rt_multi_create(ids, len(devices), 1 if rehearse_rccl else 0, C.byref(self._m)):
+            raise RtError(self.lib.rt_last_error().decode())
+        self.n = self.lib.rt_multi_size(self._m)
+        self.transport = self.lib.rt_multi_transport(self._m).decode()
+        self.rank0 = Renderer(devices[0], _borrowed_ctx=self.lib.rt_multi_context(self._m, 0))
+        self.scene = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RtError(self.lib.rt_last_error().decode())
+
+    def set_scene(self, s: FlatScene):
+        self.rank0.set_scene(s, commit=False)       # the scene goes to rank 0 only ...
+        self._check(self.lib.rt_multi_commit(self._m))  # ... one BVH build, uploaded to every GPU
+        self.scene = s
+        return self
+
+    def render(self, width, height, spp=4, max_depth=3, seed=0, jitter_mode=N.JITTER_AUTO, camera=None, chunk_samples=0,
+               collect_stats=0, want=("rgb8", "rgbf", "primid")):
+        p = N.RenderParams(width=width, height=height, spp=spp, max_depth=max_depth, seed=seed, jitter_mode=jitter_mode,
+                           tile_rank=0, tile_world=1, chunk_samples=chunk_samples, collect_stats=collect_stats)
+        cam = camera if camera is not None else self.scene.camera
+        rgb8 = np.zeros((height, width, 3), np.uint8) if "rgb8" in want else None
+        rgbf = np.zeros((height, width, 3), np.float32) if "rgbf" in want else None
+        prim = np.zeros((height, width), np.uint32) if "primid" in want else None
+        st = (N.Stats * self.n)()
+        self._check(self.lib.rt_multi_render(self._m, C.byref(cam), C.byref(p), _p(rgb8), _p(rgbf), _p(prim), C.cast(st, C.c_void_p)))
+        return dict(rgb8=rgb8, rgbf=rgbf, primid=prim, stats=[x.as_dict() for x in st])
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self.rank0.close()
+            self.lib.rt_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

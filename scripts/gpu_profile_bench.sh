@@ -1,5 +1,5 @@
 # rocprofv3 evidence for the bench.py workload: kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes -> gpurun_out/$1
-tag=${1:-prof_r01}
+tag=${1:-prof_r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-roofline > gpurun_out/$tag/trace.log 2>&1 || { tail -5 gpurun_out/$tag/trace.log; exit 1; }

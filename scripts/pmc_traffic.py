@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; both in KiB) of one bench.py frame.
 
-    python scripts/pmc_traffic.py FETCH_DIR WRITE_DIR "workload string" > profiles/r01_pmc_traffic.json
+    python scripts/pmc_traffic.py FETCH_DIR WRITE_DIR "workload string" > profiles/r02_pmc_traffic.json
 
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests as 64 bytes for wide coalesced
 reads, so it is doubled; WRITE_SIZE is taken as is.  Both raw values are kept in the output."""
@@ -25,7 +25,10 @@ def collect(d, counter):
 
 fetch, calls = collect(sys.argv[1], "FETCH_SIZE")
 write, _ = collect(sys.argv[2], "WRITE_SIZE")
-out = {"workload": sys.argv[3], "unit": "bytes", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)",
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd._native import kernel_source_hash
+out = {"workload": sys.argv[3], "kernel_source_hash": kernel_source_hash(), "unit": "bytes", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)",
        "kernels": {}}
 for k in sorted(fetch):
     if not k.startswith("k_"):

@@ -1,0 +1,90 @@
+"""BASELINE.json configs[4] (C5): the competition meshes replicated 733 times on a lattice -- 49 992 066 triangles --
+committed and rendered under -m gpu at its stated scene size.  The frame is reduced (the full
+7680x4320 @256 spp frame is 8.5 G samples: 7.9 s on one GPU, profiles/r01_configs.md); everything that depends on the
+SCENE size is exercised: the parallel host BVH build (MeshLoader.h:218-263 replaced), 28-bit record indices, a tree of
+depth 20, LDS stack rows + global spill rows, long shadow walks split into work items.  Synthetic scene without a
+reference counterpart, so the checks are size-independent properties here and the pinned oracle on the
+4.4 M-triangle version (stress:64) below."""
+import numpy as np
+import pytest
+
+from conftest import get_scene, image_metrics
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c5_733_replicas_commit_and_render():
+    from raytracer_amd.renderer import Renderer
+    scene = get_scene("stress:733", False)
+    assert scene.n_triangles == 733 * 68202 == 49992066
+    r = Renderer(0).set_scene(scene)
+    cs = r.commit_stats()
+    print(f"stress:733 commit: BVH build {cs['ms_bvh_build'] / 1e3:.1f} s, reference order {cs['ms_reference_order'] / 1e3:.2f} s, "
+          f"records {cs['ms_records'] / 1e3:.1f} s, upload {cs['ms_upload'] / 1e3:.2f} s; {cs['bvh_nodes']} nodes")
+    assert cs["n_triangles"] == scene.n_triangles and cs["bvh_nodes"] > scene.n_triangles // 8
+    w, h = 960, 540
+    a = r.render(w, h, spp=4, collect_stats=1, want=("rgb8", "primid"))
+    b = r.render(w, h, spp=4, chunk_samples=1 << 18, collect_stats=1, want=("rgb8", "primid"))  # other chunking
+    c = r.render(w, h, spp=4, want=("rgb8", "primid"))                                        # plain build of the kernels
+    for other in (b, c):
+        assert np.array_equal(a["rgb8"], other["rgb8"]) and np.array_equal(a["primid"], other["primid"])
+    sa, sb = a["stats"], b["stats"]
+    print(f"stress:733 {w}x{h}@4: {sa['ms_total']:.1f} ms, {sa['rays_closest']} + {sa['rays_shadow']} rays, depth {sa['bvh_depth']}, "
+          f"max stack {sa['bvh_max_stack']}, longest walks {sa['max_walk_closest']} / {sa['max_walk_any']}, split items {sa['split_items']}")
+    assert sa["n_triangles"] == scene.n_triangles and sa["bvh_depth"] >= 18
+    assert sa["primary_samples"] == sb["primary_samples"] == w * h * 4
+    for k in ("rays_closest", "rays_shadow", "shadow_culled", "hits_shaded"):
+        assert sa[k] == sb[k] == c["stats"][k], k
+    assert sa["queue_overflow"] == sb["queue_overflow"] == 0
+    assert sa["hits_shaded"] <= sa["rays_closest"] and sa["rays_closest"] >= sa["primary_samples"]
+    assert sa["bvh_max_stack"] > 16       # deeper than the LDS stack rows: the global spill rows are in use
+    assert sa["split_items"] > 0          # horizon pixels cast shadow rays that walk for thousands of steps: split
+    assert sa["max_walk_any"] < 20000     # ... instead of holding a launch for 700 000 steps (profiles/r01_configs.md)
+    hit = (a["primid"] != 0xFFFFFFFF).mean()
+    assert hit > 0.5
+    r.close()
+
+
+def test_c5_lite_sampled_tiles_against_the_oracle_without_packets(monkeypatch, oracle_for):
+    """stress:64 (4.4 M triangles) at 1920x1080: 16x16 tiles sampled over the whole frame against the pinned oracle, with
+    the packet kernel off (RT_PACKET_LEVELS=0,0, read at rt_commit): the per-lane kernels trace the primary rays too."""
+    import torch
+    from raytracer_amd.renderer import Renderer
+    monkeypatch.setenv("RT_PACKET_LEVELS", "0,0")
+    name, W, H, spp = "stress:64", 1920, 1080, 4
+    scene = get_scene(name, False)
+    r = Renderer(0).set_scene(scene)
+    tx, ty = (W + 15) // 16, (H + 15) // 16
+    world, rank = 509, 211   # 8160 tiles -> 16 of them, spread over the frame
+    n = r.tile_counts(W, H, rank, world)[0]
+    t8 = torch.zeros(n, 256, 3, dtype=torch.uint8, device="cuda:0")
+    tp = torch.zeros(n, 256, dtype=torch.int32, device="cuda:0")
+    st = r.render_tiles_device(W, H, rank, world, t8.data_ptr(), 0, tp.data_ptr(), spp=spp, collect_stats=1)
+    torch.cuda.synchronize()
+    ref = oracle_for(name, lazy=False).render(W, H, spp=spp, max_depth=3, tile_rank=rank, tile_world=world)
+    tiles = list(range(rank, tx * ty, world))
+    assert len(tiles) == n >= 16
+    g8, gp = t8.cpu().numpy(), tp.cpu().numpy().view(np.uint32)
+    ref8, refp = np.zeros_like(g8), np.zeros_like(gp)
+    for k, t in enumerate(tiles):
+        y0, x0 = (t // tx) * 16, (t % tx) * 16
+        blk8 = np.zeros((16, 16, 3), np.uint8)
+        blkp = np.full((16, 16), 0xFFFFFFFF, np.uint32)
+        s8, sp = ref["rgb8"][y0:y0 + 16, x0:x0 + 16], ref["primid"][y0:y0 + 16, x0:x0 + 16]
+        blk8[:s8.shape[0], :s8.shape[1]] = s8
+        blkp[:sp.shape[0], :sp.shape[1]] = sp
+        ref8[k], refp[k] = blk8.reshape(256, 3), blkp.reshape(256)
+    inside = np.zeros((n, 256), bool)  # pixels of ragged edge tiles that lie outside the image are not compared
+    for k, t in enumerate(tiles):
+        y0, x0 = (t // tx) * 16, (t % tx) * 16
+        m = np.zeros((16, 16), bool)
+        m[:min(16, H - y0), :min(16, W - x0)] = True
+        inside[k] = m.reshape(256)
+    ids = float((gp == refp)[inside].mean())
+    frac, psnr = image_metrics(g8[inside].reshape(-1, 1, 3), ref8[inside].reshape(-1, 1, 3))
+    print(f"{name} {W}x{H}: {len(tiles)} sampled tiles, primid {ids:.5f} rgb8<=1 {frac:.5f} psnr {psnr:.2f} dB; "
+          f"{st['n_triangles']} triangles, max stack {st['bvh_max_stack']}, packets off, split items {st['split_items']}")
+    assert st["n_triangles"] == 64 * 68202 and st["queue_overflow"] == 0
+    assert sum(st["prof_packet_closest"]) == 0  # no packet ran
+    assert ids >= 0.9999 and frac >= 0.999 and psnr >= 50.0
+    r.close()
