@@ -2,12 +2,22 @@
 #include "Scene.h"
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
 std::vector<Light *> lights;
 glm::vec3 ambient_light(0.7f);  // main.cpp:37
 std::vector<Object *> objects;
+
+IngestTimings &lastIngest() {
+    static IngestTimings t;
+    return t;
+}
+double ingestNowMs() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static void rtCheck(int rc, const char *what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + rt_last_error());
@@ -139,6 +149,7 @@ FlatScene flattenScene(const std::vector<Object *> &objs, const std::vector<Ligh
 }
 
 void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir, bool commit) {
+    const double t_set0 = ingestNowMs();
     rtCheck(rt_set_materials(ctx, (int32_t)s.materials.size(), s.materials.data()), "rt_set_materials");
     rtCheck(rt_set_object_materials(ctx, (int32_t)s.object_material.size(), s.object_material.data()), "rt_set_object_materials");
     rtCheck(rt_set_triangles(ctx, s.triangleCount(), s.v0.data(), s.v1.data(), s.v2.data(), s.nA.data(), s.nB.data(),
@@ -148,14 +159,28 @@ void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture
     rtCheck(rt_set_cones(ctx, (int32_t)s.cone_object.size(), s.cone_M.data(), s.cone_Minv.data(), s.cone_N.data(), s.cone_object.data()), "rt_set_cones");
     rtCheck(rt_set_planes(ctx, (int32_t)s.pl_object.size(), s.pl_point.data(), s.pl_normal.data(), s.pl_object.data()), "rt_set_planes");
     rtCheck(rt_set_lights(ctx, (int32_t)(s.light_pos.size() / 3), s.light_pos.data(), s.light_color.data(), s.ambient), "rt_set_lights");
+    lastIngest().ms_set = ingestNowMs() - t_set0;
     if (s.uses_bmp) {  // Textures.h:168-171
+        const double t0 = ingestNowMs();
         const char *names[4] = {"basecolor.bmp", "normal.bmp", "roughness.bmp", "ambientOcclusion.bmp"};
         for (int slot = 0; slot < 4; slot++) {
             BmpImage img = readBmp(texture_dir + "/" + names[slot]);
             rtCheck(rt_set_bmp(ctx, slot, img.width, img.height, img.channels, img.pixels.data()), "rt_set_bmp");
         }
+        lastIngest().ms_bmp = ingestNowMs() - t0;
     }
-    if (commit) rtCheck(rt_commit(ctx), "rt_commit");
+    if (commit) {
+        rtCheck(rt_commit(ctx), "rt_commit");
+        rtCheck(rt_get_commit_stats(ctx, &lastIngest().commit), "rt_get_commit_stats");
+    }
+}
+
+void printIngest(std::FILE *f) {
+    const IngestTimings &t = lastIngest();
+    std::fprintf(f, "ingest: %d .obj files parsed in %.1f ms, flatten %.1f ms, BMP decode %.1f ms, rt_set_* %.1f ms, BVH build %.1f ms "
+                    "(%llu triangles -> %llu nodes), reference order %.1f ms, records %.1f ms, upload %.1f ms\n",
+                 t.meshes, t.ms_parse, t.ms_flatten, t.ms_bmp, t.ms_set, t.commit.ms_bvh_build, (unsigned long long)t.commit.n_triangles,
+                 (unsigned long long)t.commit.bvh_nodes, t.commit.ms_reference_order, t.commit.ms_records, t.commit.ms_upload);
 }
 
 rt_context *defaultContext() {
@@ -256,10 +281,17 @@ static rt_context *rendererContext(const std::vector<int> &devices) {
 static void ensureUploaded(rt_context *ctx, const std::string &texture_dir) {
     const uint64_t print = sceneFingerprint(texture_dir);
     if (g_uploaded && print == g_uploaded_print) return;
+    const double t_f0 = ingestNowMs();
     FlatScene s = flattenScene(objects, lights, ambient_light);
+    lastIngest().ms_flatten = ingestNowMs() - t_f0;
     const bool multi = g_multi && ctx == rt_multi_context(g_multi, 0);
     uploadScene(ctx, s, texture_dir, !multi);
-    if (multi) rtCheck(rt_multi_commit(g_multi), "rt_multi_commit");  // BVH built once, uploaded to every GPU
+    if (multi) {
+        rtCheck(rt_multi_commit(g_multi), "rt_multi_commit");  // BVH built once, uploaded to every GPU
+        rtCheck(rt_get_commit_stats(ctx, &lastIngest().commit), "rt_get_commit_stats");
+    }
+    if (const char *v = std::getenv("RT_VERBOSE"))
+        if (std::atoi(v) > 0) printIngest(stderr);
     rt_set_host_texture_context(ctx);
     g_uploaded_print = print;
     g_uploaded = true;
@@ -340,4 +372,5 @@ void clearScene() {
     lights.clear();
     ambient_light = glm::vec3(0.7f);
     g_uploaded = false;
+    lastIngest() = IngestTimings{};
 }

@@ -7,6 +7,7 @@
 // intersects or shades on the CPU.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -91,6 +92,21 @@ rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt = R
 glm::vec3 trace_ray(Ray ray, int bounces);
 // Batched form; also returns the closest hits when `hits` is given.
 std::vector<glm::vec3> trace_rays(const std::vector<Ray> &rays, int bounces, std::vector<Hit> *hits = nullptr);
+
+// Where the time between "program start" and "first pixel" went (the reference's one timer lumps all of it with the
+// render, main.cpp:541,651-653): filled by the built-in scene functions (parse) and by render()'s upload; printed by
+// raytracer_hip and under RT_VERBOSE=1.
+struct IngestTimings {
+    int meshes = 0;
+    double ms_parse = 0;      // .obj files -> Triangle lists (MeshLoader ctor; files parsed concurrently)
+    double ms_flatten = 0;    // object list -> SoA arrays of the C ABI
+    double ms_bmp = 0;        // BMP decode of the four maps (only when a material samples them)
+    double ms_set = 0;        // rt_set_*: copies into the context
+    rt_commit_stats commit{}; // BVH build / reference order / records / upload (rt_get_commit_stats)
+};
+IngestTimings &lastIngest();
+double ingestNowMs();
+void printIngest(std::FILE *f);
 
 // Built-in scenes, restated from the reference through the surface above (Scenes.cpp).
 Camera sampleScene(const std::string &meshDir = "./meshes");         // main.cpp:258-407

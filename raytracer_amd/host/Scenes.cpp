@@ -5,6 +5,9 @@
 // commented-out blocks of main() (main.cpp:570-578, 633-638).
 #include "Scene.h"
 
+#include <exception>
+#include <thread>
+
 namespace {
 
 Material withAmbientDiffuseSpecular(glm::vec3 a, glm::vec3 d, glm::vec3 s) {
@@ -22,7 +25,38 @@ void addSphere(const Material &m, glm::vec3 centre, float radius) {
 }
 
 void addMesh(const std::string &dir, const char *file, glm::vec3 at, const Material &m) {
+    const double t0 = ingestNowMs();
     objects.push_back(new MeshLoader(dir + "/" + file, at, true, m));
+    lastIngest().ms_parse += ingestNowMs() - t0;
+    lastIngest().meshes++;
+}
+
+// Several meshes at once: .obj parsing is the largest part of loading the competition scene (16 files, ~160 ms of
+// sscanf on one core -- profiles/r02_ingest.md), the files are independent, so each is parsed on a thread of its own;
+// the objects enter `objects` in the given order (the first object wins distance ties, main.cpp:67).
+struct MeshJob { std::string path; glm::vec3 at; const Material *m; };
+void addMeshes(const std::vector<MeshJob> &jobs) {
+    std::vector<MeshLoader *> out(jobs.size(), nullptr);
+    std::vector<std::exception_ptr> err(jobs.size());
+    const double t0 = ingestNowMs();
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < jobs.size(); k++)
+        th.emplace_back([&, k] {
+            try {
+                out[k] = new MeshLoader(jobs[k].path, jobs[k].at, true, *jobs[k].m);
+            } catch (...) {
+                err[k] = std::current_exception();
+            }
+        });
+    for (std::thread &t : th) t.join();
+    for (size_t k = 0; k < jobs.size(); k++)
+        if (err[k]) {
+            for (MeshLoader *m : out) delete m;
+            std::rethrow_exception(err[k]);
+        }
+    for (MeshLoader *m : out) objects.push_back(m);
+    lastIngest().ms_parse += ingestNowMs() - t0;
+    lastIngest().meshes += (int)jobs.size();
 }
 
 void addLight(glm::vec3 p, float intensity) { lights.push_back(new Light(p, glm::vec3(intensity))); }
@@ -214,7 +248,9 @@ void competitionGroundAndLights(const CompetitionMaterials &M) {
 
 Camera competitionScene(const std::string &meshDir) {
     CompetitionMaterials M;
-    for (const MeshPlacement &p : kCompetitionMeshes) addMesh(meshDir, p.file, glm::vec3(p.x, p.y, p.z), M.*(p.mat));
+    std::vector<MeshJob> jobs;
+    for (const MeshPlacement &p : kCompetitionMeshes) jobs.push_back({meshDir + "/" + p.file, glm::vec3(p.x, p.y, p.z), &(M.*(p.mat))});
+    addMeshes(jobs);
     competitionGroundAndLights(M);
     return competitionCamera();
 }
@@ -281,8 +317,13 @@ Camera coneScene(const std::string &meshDir) {
 // reference counterpart).  replica r sits at lattice cell (ix, iz) with spacing 3.5 in x and z.
 Camera stressScene(const std::string &meshDir, int replicas) {
     CompetitionMaterials M;
+    std::vector<MeshJob> jobs;
+    for (const MeshPlacement &p : kCompetitionMeshes) jobs.push_back({meshDir + "/" + p.file, glm::vec3(p.x, p.y, p.z), &(M.*(p.mat))});
+    const size_t before = objects.size();
+    addMeshes(jobs);  // parsed concurrently, then taken back out of `objects`: they are the templates of the lattice
     std::vector<MeshLoader *> base;
-    for (const MeshPlacement &p : kCompetitionMeshes) base.push_back(new MeshLoader(meshDir + "/" + p.file, glm::vec3(p.x, p.y, p.z), true, M.*(p.mat)));
+    for (size_t k = before; k < objects.size(); k++) base.push_back(static_cast<MeshLoader *>(objects[k]));
+    objects.resize(before);
     int side = 1;
     while (side * side < replicas) side++;
     for (int r = 0; r < replicas; r++) {

@@ -65,6 +65,7 @@ int main(int argc, const char *argv[]) {
         std::cout << "It took " << std::chrono::duration<double>(t2 - t0).count() << " seconds to render the image (scene load "
                   << std::chrono::duration<double>(t1 - t0).count() << " s, GPU " << st.ms_total << " ms, "
                   << rays / st.ms_total / 1e3 << " Mrays/s)" << std::endl;
+        printIngest(stdout);  // what the reference's one timer lumps together (main.cpp:541)
         if (p3) image.writeImage(out.c_str());
         else image.writeImageBinary(out.c_str());
         clearScene();

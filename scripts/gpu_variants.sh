@@ -8,7 +8,8 @@ for so in /tmp/base.so build_variants/*.so; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/variants/$name.json"))
-print("$name", round(d["ms_per_step"],1), "ms", {k:round(v,1) for k,v in d["kernel_ms"].items() if k in ("ms_closest","ms_shade","ms_any")}, flush=True)
+l=d["roofline"].get("lanes",{})
+print("$name", round(d["ms_per_step"],1), "ms", round(d["value"]), "Mrays/s", {k:round(v,1) for k,v in d["kernel_ms"].items() if k in ("ms_packet","ms_closest","ms_shade","ms_any")}, "lanes %.1f/%.1f" % (l.get("lanes_per_node_phase",0), l.get("lanes_per_triangle_phase",0)), flush=True)
 PY
 done
 cp /tmp/base.so raytracer_amd/csrc/libraytracer_hip.so
