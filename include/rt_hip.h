@@ -97,7 +97,7 @@ typedef struct rt_render_params {
 typedef struct rt_stats {
     uint64_t primary_samples;
     uint64_t rays_closest;    /* primary + reflection + refraction rays traced (Ray ctor at main.cpp:156,183,642) */
-    uint64_t rays_shadow;     /* shadow rays traced (Ray ctor at main.cpp:49; back-face culled ones are not rays) */
+    uint64_t rays_shadow;     /* shadow rays traced (Ray ctor at main.cpp:49; back-face culled ones are not rays; see shadow_zero) */
     uint64_t shadow_culled;   /* lights rejected by main.cpp:44-46 */
     uint64_t hits_shaded;     /* PhongModel invocations */
     uint64_t nodes_visited;   /* BVH nodes fetched by closest-hit rays  (collect_stats & 1 only) */
@@ -129,6 +129,9 @@ typedef struct rt_stats {
     double ms_packet;           /* packet kernel of the closest-hit queues (collect_stats & 2); ms_closest is the per-lane kernel alone */
     uint64_t shadow_unoccluded; /* shadow rays that reached their light, i.e. accumulator updates (collect_stats & 1 only) */
     uint64_t split_items;       /* work items that long shadow walks were split into (0 in most frames) */
+    uint64_t shadow_zero;       /* shadow rays the reference casts (Ray ctor at main.cpp:49) that are NOT traced here because their
+                                   pending radiance is exactly zero (e.g. main.cpp:172 with refraction 1): rays_shadow + shadow_zero
+                                   is the reference's shadow-ray count */
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

@@ -240,6 +240,7 @@ void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
     st->rays_closest -= c[RT_CNT_INVALID];  // slots of pixels outside the image and unused slab slots are not rays
     st->rays_shadow -= c[RT_CNT_SHADOW_HOLES];
     st->shadow_culled += c[RT_CNT_CULLED];
+    st->shadow_zero += c[RT_CNT_ZERO];
     st->shadow_unoccluded += u64at(RT_CNT_UNOCCLUDED);
     for (int d = 0; d <= max_depth && d < 16; d++)
         for (int r = 0; r <= RT_SPLIT_ROUNDS; r++) st->split_items += c[RT_CNT_SPLIT(d, r)];

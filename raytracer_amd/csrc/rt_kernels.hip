@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     const int remaining = max_depth - level;
     const uint32_t lane = laneId();
     const int nlights = sc.n_lights;
-    uint32_t culled = 0, shaded = 0;
+    uint32_t culled = 0, shaded = 0, zero = 0;
     // PROF build: shader clocks per section, summed over waves: [0] loads + hit reconstruction, [1] material, light
     // culling, textures, ambient, bounce set-up, [2] (unused since the slabs), [3] shadow-ray emission,
     // [4] next-level emission, [5] iterations
@@ -1208,30 +1208,23 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         RT_PROF_MARK(1)
         RT_PROF_MARK(2)
         // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray ----
+        // A shadow ray whose pending radiance is exactly zero cannot change the image: whether it reaches the light or
+        // not, zero is added.  The reference still casts it (is_shadowed runs before the colour is computed,
+        // main.cpp:100-103) -- and it is common: `color *= 1 - refraction` (main.cpp:172) zeroes the whole direct term
+        // of every material with refraction 1 (crystal, the refractive floor, glass) wherever bounces remain, i.e. all
+        // their shadow rays above the last level.  Such rays are not emitted; they are counted (shadow_zero) so that
+        // traced + zero equals the reference's count.  Exactly zero means: a factor of the product is exactly zero (the
+        // product is then +-0 or, for an infinite / NaN direct term, NaN -- which rtToFixed drops: zero either way), or
+        // the computed colour is +-0 in all three channels.  Results are bit-identical.
+        const bool deadDirect = directScale == 0.0f || directScale2 == 0.0f || weight == 0.0f;
         for (int l = 0; l < nlights; l++) {
             // is_shadowed's back-face test (main.cpp:44-46): a light behind the surface casts no shadow ray
             const V3 lp = ld3(sc.lights[l].pos), toL = lp - P;
             const V3 ld = normalize(toL);                            // main.cpp:97
-            const bool lit = active && !(dot(normal, ld) < 0);
-            if (active && !lit) culled++;
-            const unsigned long long mask = __ballot(lit);
-            if (!mask) continue;  // wave-uniform
-            const uint32_t c = (uint32_t)__popcll(mask), rank = maskRankBelow(mask);
-            uint32_t cur = __builtin_amdgcn_readlane(curv, l), end = __builtin_amdgcn_readlane(endv, l);
-            const uint32_t room = end - cur;
-            uint32_t slot = cur + rank;
-            if (c > room) {  // the slab is used up to its last slot, the rest of the rays opens the next one
-                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(level), slabS);
-                if (rank >= room) slot = nbase + (rank - room);
-                cur = nbase + (c - room);
-                end = nbase + slabS;
-            } else {
-                cur += c;
-            }
-            if (lane == (uint32_t)l) {
-                curv = cur;
-                endv = end;
-            }
+            const bool faces = active && !(dot(normal, ld) < 0);
+            if (active && !faces) culled++;
+            bool lit = faces && !deadDirect;
+            V3 c3 = v3s(0.0f);
             if (lit) {
                 const V3 lc = ld3(sc.lights[l].color);
                 const float dl = length(toL);                        // :98
@@ -1254,10 +1247,32 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                     const float specular = RT_COLOR_POW_MAX0(dot(hv, ns), 4 * shiny);
                     spec = attenuation * lc * mspec * specular;
                 }
-                V3 c3 = diffusion + spec;
+                c3 = diffusion + spec;
                 c3 = c3 * directScale;   // x * 1.0f is exact when no scaling applies
                 c3 = c3 * directScale2;
                 c3 = c3 * weight;
+                if (c3.x == 0.0f && c3.y == 0.0f && c3.z == 0.0f) lit = false;  // (a light the shading normal faces away from: diffuse 0)
+            }
+            if (faces && !lit) zero++;
+            const unsigned long long mask = __ballot(lit);
+            if (!mask) continue;  // wave-uniform
+            const uint32_t c = (uint32_t)__popcll(mask), rank = maskRankBelow(mask);
+            uint32_t cur = __builtin_amdgcn_readlane(curv, l), end = __builtin_amdgcn_readlane(endv, l);
+            const uint32_t room = end - cur;
+            uint32_t slot = cur + rank;
+            if (c > room) {  // the slab is used up to its last slot, the rest of the rays opens the next one
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(level), slabS);
+                if (rank >= room) slot = nbase + (rank - room);
+                cur = nbase + (c - room);
+                end = nbase + slabS;
+            } else {
+                cur += c;
+            }
+            if (lane == (uint32_t)l) {
+                curv = cur;
+                endv = end;
+            }
+            if (lit) {
                 if (slot < q.shadow_cap) {  // 32-byte record: point + (sample, light), pending colour (rtShadowRay rebuilds the ray)
                     q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | ((uint32_t)l << 28)));
                     q.shC[slot] = make_float4(c3.x, c3.y, c3.z, 0.0f);
@@ -1341,12 +1356,14 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     // statistics: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) {
         culled += __shfl_down(culled, off);
+        zero += __shfl_down(zero, off);
         shaded += __shfl_down(shaded, off);
         holesS += __shfl_down(holesS, off);
         holesR += __shfl_down(holesR, off);
     }
     if (lane == 0) {
         if (culled) atomicAdd(q.counters + RT_CNT_CULLED, culled);
+        if (zero) atomicAdd(q.counters + RT_CNT_ZERO, zero);
         if (shaded) atomicAdd(q.counters + RT_CNT_SHADED, shaded);
         if (holesS) atomicAdd(q.counters + RT_CNT_SHADOW_HOLES, holesS);
         if (holesR) atomicAdd(q.counters + RT_CNT_INVALID, holesR);  // ray-queue holes are invalid slots like those of k_gen_primary

@@ -193,6 +193,7 @@ struct RtQueues {
 #define RT_CNT_PROF_PACKET_CLOSEST (73 * RT_CNT_STRIDE)      // 8 x u64 packet statistics of k_packet<closest> (stats build)
 #define RT_CNT_PROF_PACKET_ANY (74 * RT_CNT_STRIDE)          // same for shadow packets
 #define RT_CNT_SHADOW_HOLES (75 * RT_CNT_STRIDE)             // unused slab slots of the shadow queues (not rays)
+#define RT_CNT_ZERO (75 * RT_CNT_STRIDE + 8)                 // shadow rays not emitted because their pending radiance is exactly zero
 #define RT_CNT_UNOCCLUDED (75 * RT_CNT_STRIDE + 4)           // u64: shadow rays that reached their light (stats build)
 #define RT_CNT_RESID_CLOSEST(d) ((76 + (d)) * RT_CNT_STRIDE) // rays of level d handed to the per-lane closest-hit kernel
 #define RT_CNT_RESID_ANY(d) ((92 + (d)) * RT_CNT_STRIDE)     // same for shadow rays

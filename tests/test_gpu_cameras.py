@@ -45,7 +45,7 @@ def test_random_cameras(name, spread):
             frac, psnr = image_metrics(gpu["rgb8"], cpu["rgb8"])
             hit = (gpu["primid"] != N.PRIM_MISS).mean()
             print(f"{name} camera {k}: {hit:.2f} of the pixels hit, primid {ids:.6f} rgb8<=1 {frac:.6f} psnr {psnr:.2f} dB")
-            assert gpu["stats"]["rays_closest"] == cpu["stats"]["rays_closest"] and gpu["stats"]["rays_shadow"] == cpu["stats"]["rays_shadow"]
+            assert gpu["stats"]["rays_closest"] == cpu["stats"]["rays_closest"] and gpu["stats"]["rays_shadow"] + gpu["stats"]["shadow_zero"] == cpu["stats"]["rays_shadow"]
             assert ids >= 0.9999 and frac >= 0.999 and psnr >= 50.0
     finally:
         r.close()

@@ -26,7 +26,7 @@ def check(scene, w, h, spp=4, depth=3, label=""):
     st = gpu["stats"]
     print(f"{label}: primid {ids:.6f} rgb8<=1 {frac:.6f} psnr {psnr:.2f} dB, rays {st['rays_closest']} + {st['rays_shadow']}")
     assert st["queue_overflow"] == 0
-    assert st["rays_closest"] == cpu["stats"]["rays_closest"] and st["rays_shadow"] == cpu["stats"]["rays_shadow"]
+    assert st["rays_closest"] == cpu["stats"]["rays_closest"] and st["rays_shadow"] + st["shadow_zero"] == cpu["stats"]["rays_shadow"]
     assert ids >= 0.9999 and frac >= 0.999 and psnr >= 50.0
     return gpu, cpu
 
