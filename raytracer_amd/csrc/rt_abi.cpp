@@ -85,6 +85,8 @@ struct rt_context {
     // committed scene
     bool committed = false;
     rt_commit_stats commit_stats{};
+    uint64_t plane_general = 0;  // planes / scene with hits for the general k_shade (commitHost)
+    bool has_general = false;
     struct { uint64_t n_nodes = 0, n_triangles = 0; } info;  // (a replica of rt_multi keeps no triangle arrays / tree of its own)
     RtBvh bvh;
     std::vector<int64_t> mesh_first;  // per object: first global triangle index (or -1)
@@ -92,6 +94,7 @@ struct rt_context {
     DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part
     DevBuf<RtNodeP> d_nodes_p;  // float-box form of the nodes (packet kernels)
     DevBuf<uint32_t> d_resid;   // queue indices of the rays the packet kernels hand to the per-lane kernels
+    DevBuf<uint32_t> d_general; // queue indices of the hits the fast k_shade leaves to the general one
     DevBuf<uint2> d_split[2];   // work items of split any-hit walks (rt_kernels.hip), ping-pong by round
     DevBuf<RtTriShade> d_shade;
     DevBuf<RtSphere> d_spheres;
@@ -135,10 +138,11 @@ struct QueueSizes {
 QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl) {
     QueueSizes z;
     const size_t waves = (size_t)rtShadeWaves(ctx->cfg);
-    z.ray_cap = samples * fanout + waves * RT_SLAB_MAX + samples * fanout / 64 + 128;
-    z.sh_cap = samples * fanout * nl + waves * nl * RT_SLAB_MAX;
+    // (x 2: the fast and the general instance of k_shade both reserve slabs)
+    z.ray_cap = samples * fanout + 2 * waves * RT_SLAB_MAX + samples * fanout / 64 + 128;
+    z.sh_cap = samples * fanout * nl + 2 * waves * nl * RT_SLAB_MAX;
     z.fits32 = z.ray_cap < (1ull << 32) && z.sh_cap < (1ull << 32);
-    z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8) + z.sh_cap * 32 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
+    z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + z.sh_cap * 32 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
     return z;
 }
 
@@ -164,6 +168,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
         if (ctx->d_accum.alloc(samples * 3)) return 1;
         if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
         if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
+        if (ctx->d_general.alloc(ray_cap)) return 1;
         return 0;
     };
     size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
@@ -171,14 +176,14 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     if (grow() || ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) {
         const std::string why = g_err;
         for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); ctx->d_split[k].release(); }
-        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_resid.release();
+        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_resid.release(); ctx->d_general.release();
         ctx->ws_samples = 0;
         ctx->ws_bytes = 0;
         ctx->q = RtQueues{};
         ctx->q.spill = ctx->d_spill.p;
         return fail("workspace allocation failed (workspace released): " + why);
     }
-    ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8) + sh_cap * 32 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
+    ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + sh_cap * 32 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
     ctx->ws_samples = samples;
     RtQueues &q = ctx->q;
     for (int k = 0; k < 2; k++) {
@@ -193,6 +198,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights
     q.counters = ctx->d_counters.p;
     q.spill = ctx->d_spill.p;
     q.resid = ctx->d_resid.p;
+    q.general = ctx->d_general.p;
     q.split[0] = ctx->d_split[0].p;
     q.split[1] = ctx->d_split[1].p;
     q.split_cap = (uint32_t)split_cap;
@@ -476,7 +482,7 @@ int rt_destroy(rt_context *ctx) {
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
-    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release();
+    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_general.release();
     ctx->d_counters.release(); ctx->d_chunk_counters.release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -661,6 +667,20 @@ int commitHost(rt_context *ctx, CommitImage &img) {
     for (int k = 0; k < 4; k++)
         if (needs_bmp[k] && ctx->bmp_w[k] == 0) return fail("rt_commit: a material samples a BMP map that was not set (rt_set_bmp)");
 
+    // materials whose hits the fast k_shade leaves to the general instance (rt_kernels.hip): BMP maps, anisotropic branch
+    std::vector<uint8_t> general_mat((size_t)n_mat, 0);
+    for (int k = 0; k < n_mat; k++) {
+        const rt_material &m = ctx->materials[k];
+        general_mat[k] = m.is_anisotropic || m.has_img_texture || m.texture >= RT_TEX_BMP_COLOR ||
+                         (m.has_normal_map && m.normal_map >= RT_TEX_BMP_COLOR);
+    }
+    ctx->plane_general = 0;
+    for (size_t k = 0; k < ctx->planes.size(); k++)
+        if (general_mat[(size_t)ctx->planes[k].material]) ctx->plane_general |= 1ull << k;
+    ctx->has_general = !img.units.empty() || ctx->plane_general != 0;
+    for (int64_t k = 0; k < nt && !ctx->has_general; k++)
+        if (general_mat[(size_t)ctx->object_material[(size_t)ctx->tri_object[k]]]) ctx->has_general = true;
+
     // acceleration structure + reordered triangle records
     rtBuildBvh(nt, ctx->v0.data(), ctx->v1.data(), ctx->v2.data(), ctx->bvh);
     const double t1 = nowMs();
@@ -692,7 +712,7 @@ int commitHost(rt_context *ctx, CommitImage &img) {
         g.object = (uint32_t)ctx->tri_object[t];
         g.rank = rank[t];
         g.prim = (uint32_t)t;
-        g._pad = 0;
+        g.general = general_mat[(size_t)ctx->object_material[(size_t)ctx->tri_object[t]]] ? RT_ID_GENERAL : 0u;
         RtTriShade &s = img.shade[slot];
         std::memcpy(s.nA, &ctx->nA[3 * t], 12); std::memcpy(s.nB, &ctx->nB[3 * t], 12); std::memcpy(s.nC, &ctx->nC[3 * t], 12);
         std::memcpy(s.tA, &ctx->tA[2 * t], 8); std::memcpy(s.tB, &ctx->tB[2 * t], 8); std::memcpy(s.tC, &ctx->tC[2 * t], 8);
@@ -762,6 +782,8 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     d.n_lights = (int)src->lights.size();
     d.n_objects = (int)src->object_material.size();
     d.n_materials = (int)src->materials.size();
+    d.plane_general = src->plane_general;
+    d.has_general = src->has_general ? 1 : 0;
     // traversal stack: up to RT_LDS_STACK rows per lane in LDS (16 KB per 256-thread block), the rest of the worst case
     // (sum of children - 1 along the deepest path; rarely reached) in a global spill area per grid thread
     const int entries = std::max(1, std::min(src->bvh.max_stack, RT_LDS_STACK));
@@ -847,8 +869,8 @@ namespace {
 bool carveStatic(unsigned char *base, size_t bytes, size_t samples, int fanout, int nl, uint32_t *spill, RtQueues &q) {
     const size_t waves = (size_t)RT_STATIC_SHADE_BLOCKS * (RT_BLOCK / 64);
     const size_t total = samples * (size_t)fanout;
-    const size_t ray_cap = total + waves * 128 + total / 64 + 128;            // as queueSizes(), with this path's slab sizes
-    const size_t sh_cap = total * nl + waves * nl * RT_STATIC_SLAB;
+    const size_t ray_cap = total + 2 * waves * 128 + total / 64 + 128;        // as queueSizes(), with this path's slab sizes
+    const size_t sh_cap = total * nl + 2 * waves * nl * RT_STATIC_SLAB;
     if (ray_cap >= (1ull << 31) || sh_cap >= (1ull << 31)) return false;
     size_t off = 0;
     auto take = [&](size_t n) -> void * {
@@ -869,6 +891,7 @@ bool carveStatic(unsigned char *base, size_t bytes, size_t samples, int fanout, 
     q.shC = (float4 *)take(sh_cap * sizeof(float4));
     q.accum = (long long *)take(samples * 3 * sizeof(long long));
     q.resid = (uint32_t *)take(std::max(sh_cap, ray_cap) * sizeof(uint32_t));
+    q.general = (uint32_t *)take(ray_cap * sizeof(uint32_t));
     q.spill = spill;
     q.ray_cap = (uint32_t)ray_cap;
     q.shadow_cap = (uint32_t)sh_cap;

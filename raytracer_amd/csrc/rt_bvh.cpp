@@ -12,6 +12,10 @@
 // rtReferenceOrder() recomputes that order so the kernel can break ties identically.
 #include "rt_bvh.h"
 
+#ifndef RT_SAH_STEP_COST
+#define RT_SAH_STEP_COST 1.0f  // cost of a traversal step in triangle tests (leaf-vs-split decision)
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -202,7 +206,7 @@ struct Builder {
         // leaf when allowed and not worse than splitting (traversal step ~ 1 triangle test)
         if (count <= RT_LEAF_MAX) {
             const float leafCost = box.halfArea() * count;
-            if (bestAxis < 0 || bestCost + box.halfArea() >= leafCost) return makeLeaf();
+            if (bestAxis < 0 || bestCost + RT_SAH_STEP_COST * box.halfArea() >= leafCost) return makeLeaf();
         }
         uint32_t mid;
         if (bestAxis >= 0) {

@@ -124,8 +124,10 @@ RT_DEV V3 rtPixelAt(const RtSceneDev &sc, int slot, V2 uv) {
 // copy costs the caller its caller-saved registers around every call (222 ms), one inlined copy inside a rolled loop
 // over the four textures is no better (220 ms), four inlined copies are fastest (210 ms; 6.9 K VALU instructions,
 // still inside the instruction cache).  The Perlin evaluation sits in a rolled loop (opal needs three).
+// FAST: the caller guarantees that no BMP map is sampled (fast k_shade: such materials go to the general kernel)
+template <bool FAST = false>
 __device__ inline V3 rtEvalTexture(const RtSceneDev &sc, int id, V2 uv) {
-    if (id >= RT_TEX_BMP_COLOR) {  // Textures.h:173-188
+    if (!FAST && id >= RT_TEX_BMP_COLOR) {  // Textures.h:173-188
         V3 c = rtPixelAt(sc, id - RT_TEX_BMP_COLOR, uv);
         return (id >= RT_TEX_BMP_ROUGHNESS) ? v3s(c.x) : c;
     }
@@ -310,21 +312,24 @@ struct RtFullHit {
     int32_t triangle;  // slot (for meshes) or -1
 };
 
+template <bool FAST = false>
 RT_DEV V3 rtApplyNormalMap(const RtSceneDev &sc, const rt_material &m, V3 tangent, V3 bitangent, V3 normal, V2 uv) {
-    V3 nm = normalize(rtEvalTexture(sc, m.normal_map, uv));
+    V3 nm = normalize(rtEvalTexture<FAST>(sc, m.normal_map, uv));
     // mat3(T,B,N) * nm, glm/detail/type_mat3x3.inl:468-474
     V3 r = v3(tangent.x * nm.x + bitangent.x * nm.y + normal.x * nm.z, tangent.y * nm.x + bitangent.y * nm.y + normal.y * nm.z,
               tangent.z * nm.x + bitangent.z * nm.y + normal.z * nm.z);
     return normalize(r);
 }
 
+// FAST: the caller guarantees that the hit is a triangle or a plane without BMP maps (fast k_shade)
+template <bool FAST = false>
 RT_DEV void rtReconstructHit(const RtSceneDev &sc, const RtRay &r, float t, uint32_t id, RtFullHit &h) {
     h.T = v3s(0.0f);
     h.B = v3s(0.0f);
     h.uv = V2{0.0f, 0.0f};
     h.triangle = -1;
     const uint32_t kind = id & RT_ID_KIND_MASK;
-    if (kind == RT_ID_SPHERE) {  // Objects.h:67-95
+    if (!FAST && kind == RT_ID_SPHERE) {  // Objects.h:67-95
         const RtSphere &sp = sc.spheres[id & 0xFFFF];
         float dist;
         V3 ni, nn;
@@ -363,9 +368,10 @@ RT_DEV void rtReconstructHit(const RtSceneDev &sc, const RtRay &r, float t, uint
         if (m.has_normal_map) {
             h.T = v3(0, 0, 1);
             h.B = v3(1, 0, 0);
-            h.ns = rtApplyNormalMap(sc, m, h.T, h.B, h.normal, h.uv);
+            h.ns = rtApplyNormalMap<FAST>(sc, m, h.T, h.B, h.normal, h.uv);
         }
     } else {  // MeshLoader.h:89-121
+        id &= RT_ID_TRI_MASK;
         const RtTri T = rtLoadTri(sc.tri_geom, id);
         const RtTriShade &s = sc.tri_shade[id];
         V3 td = r.o + t * r.d;

@@ -180,7 +180,7 @@ RT_DEV bool rtTriStep(const RtSceneDev &sc, RtWalk &w, RtTraversalStats &st) {
                                            (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
         if (take) {
             w.best_t = t;
-            w.best_id = (w.pend & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes;
+            w.best_id = ((w.pend & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes) | __float_as_uint(q3.w);  // (| RT_ID_GENERAL flag)
             w.best_obj = obj;
             w.best_rank = rank;
         }
@@ -307,7 +307,7 @@ RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &
         float t;
         if (rtPlaneHit(pl, w.r, t) && (t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS && pl.object < w.best_obj))) {
             w.best_t = t;
-            w.best_id = RT_ID_PLANE | (uint32_t)k;
+            w.best_id = RT_ID_PLANE | (uint32_t)k | (((sc.plane_general >> k) & 1ull) ? RT_ID_GENERAL : 0u);
             w.best_obj = pl.object;
         }
     }
@@ -930,7 +930,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
                                                                (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
                             if (take) {
                                 w.best_t = t;
-                                w.best_id = first + k - (uint32_t)sc.n_nodes;
+                                w.best_id = (first + k - (uint32_t)sc.n_nodes) | tr[15];  // (| RT_ID_GENERAL flag)
                                 w.best_obj = obj;
                                 w.best_rank = rank;
                             }
@@ -1032,9 +1032,15 @@ RT_DEV float colorPowMax0(float x, float y) {
 #define RT_COS_OF_ANGLE(a, b) cosf(rtAngle((a), (b)))
 #endif
 
-template <bool PROF>
+// Two instances.  FAST (GENERAL = false) scans the level's hit records and shades triangles and planes whose material
+// needs neither a BMP map nor the anisotropic branch: without those and without the sphere / cone reconstruction
+// (double-precision asin / atan2) the kernel fits 128 VGPRs with no scratch (the full body spills 95 registers).  Hits it
+// cannot shade (RT_ID_GENERAL in the id, or a sphere / cone) go to a list (q.general) that the GENERAL instance -- the
+// full body -- works off afterwards; it is launched only for scenes that hold such primitives.
+template <bool PROF, bool GENERAL>
 __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles, uint32_t slab) {
+    constexpr bool FAST = !GENERAL;
     // Output slots come from WAVE-PRIVATE slabs: a wave reserves `slab` consecutive slots of the shadow queue per light
     // (and of the next level's ray queue) with one atomic and fills them over its next iterations -- no barrier, no
     // per-iteration atomic, and a slab holds rays towards ONE light, which keeps k_any's batches coherent.  Cursor and
@@ -1044,7 +1050,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     uint32_t curv = 0, endv = 0, holesS = 0, holesR = 0;
     const uint32_t slabS = slab, slabR = max(slab, 128u);  // one iteration emits at most 64 shadow rays per light, 128 rays
     const int buf = level & 1, nbuf = buf ^ 1;
-    const uint32_t n = min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(level)], q.ray_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
     // A wave shades SEGMENTS of consecutive queue entries (consecutive entries are neighbouring samples / hits), so the
     // rays it appends to a slab leave neighbouring points towards one light.  Segments are dealt round-robin to the
     // waves; their length adapts to the queue so that every wave still gets several.
@@ -1072,15 +1078,27 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         while (count < 64 && moreSeg) {
             const uint32_t j = scan + lane;
             const bool valid = j < segEnd;
-            const bool hit = valid && __float_as_uint(q.hits[valid ? j : 0].y) != RT_ID_MISS;
-            if (level == 0 && valid && !hit) {  // miss, or slot outside the image: the sample's first and only level-0 entry
+            // FAST: entry j of the level's ray queue; GENERAL: entry j of the list the fast instance left (all hits)
+            const uint32_t qi = GENERAL ? (valid ? q.general[j] : 0u) : j;
+            const uint32_t hid = GENERAL ? 0u : __float_as_uint(q.hits[valid ? j : 0].y);
+            bool hit = valid && (GENERAL || hid != RT_ID_MISS);
+            if (!GENERAL && level == 0 && valid && !hit) {  // miss, or slot outside the image: the sample's first and only level-0 entry
                 long long *acc = q.accum + 3ull * (__float_as_uint(q.rayB[buf][j].w) & RT_SAMPLE_MASK);
                 acc[0] = 0;
                 acc[1] = 0;
                 acc[2] = 0;
             }
+            if (!GENERAL) {  // what this instance cannot shade goes to the general one's list
+                const bool gen = hit && ((hid & RT_ID_KIND_MASK) == RT_ID_SPHERE || (hid & RT_ID_GENERAL));
+                const unsigned long long gm = __ballot(gen);
+                if (gm) {  // wave-uniform, rare
+                    const uint32_t gbase = waveReserve(q.counters + RT_CNT_GENERAL(level), (uint32_t)__popcll(gm));
+                    if (gen) q.general[gbase + maskRankBelow(gm)] = j;
+                    if (gen) hit = false;
+                }
+            }
             const unsigned long long hm = __ballot(hit);
-            if (hit) ring[(head + count + maskRankBelow(hm)) & 127u] = j;
+            if (hit) ring[(head + count + maskRankBelow(hm)) & 127u] = qi;
             count += (uint32_t)__popcll(hm);
             scan += 64;
             if (scan >= segEnd) {  // next segment of this wave
@@ -1115,7 +1133,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             uint32_t prim;
             if (kind == RT_ID_SPHERE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.spheres[id & 0xFFFF].object;
             else if (kind == RT_ID_PLANE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.planes[id & 0xFFFF].object;
-            else prim = sc.tri_shade[id].prim;
+            else prim = sc.tri_shade[id & RT_ID_TRI_MASK].prim;
             primid_tiles[(size_t)(tile0 + (pm >> 8)) * RT_TILE_PIXELS + py * RT_TILE + px] = prim;
         }
 
@@ -1137,7 +1155,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             }
             RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
             RtFullHit h;
-            rtReconstructHit(sc, r, hrec.x, id, h);
+            rtReconstructHit<FAST>(sc, r, hrec.x, id, h);
             RT_PROF_MARK(0)
             const rt_material m = sc.materials[h.material];
             P = h.P;
@@ -1149,7 +1167,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             if (dot(normal, view) < 0) normal = -normal;  // main.cpp:88-94
             if (dot(ns, view) < 0) ns = -ns;
             mspec = ld3(m.specular);
-            aniso = m.is_anisotropic != 0;
+            aniso = !FAST && m.is_anisotropic != 0;
             alpha_x = m.alpha_x;
             alpha_y = m.alpha_y;
             // (1 - reflection)(1 - refraction) scaling of the direct term (main.cpp:153,172), only with budget left
@@ -1159,17 +1177,20 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             if (hasRefr) directScale2 = 1 - m.refraction;
 
             // texture and roughness are light-independent: evaluated once (the reference re-evaluates them per light
-            // that faces the surface; a hit no light faces does not use them)
-            dcol = m.texture != RT_TEX_NONE ? rtEvalTexture(sc, m.texture, h.uv) : ld3(m.diffuse);
-            shiny = m.shininess;
-            if (m.has_img_texture) {  // main.cpp:116-117, double pow
-                const double rough = (double)rtEvalTexture(sc, m.roughness, h.uv).x;
-                const double r2 = rough * rough;
-                shiny = (float)((0.5 / (r2 * r2)) - 0.5);
+            // that faces the surface; a hit no light faces does not use them) -- and not at all where the direct term
+            // is multiplied by an exact zero (deadDirect below: no shadow ray is emitted, nothing reads dcol / shiny)
+            if (!(directScale == 0.0f || directScale2 == 0.0f || weight == 0.0f)) {
+                dcol = m.texture != RT_TEX_NONE ? rtEvalTexture<FAST>(sc, m.texture, h.uv) : ld3(m.diffuse);
+                shiny = m.shininess;
+                if (!FAST && m.has_img_texture) {  // main.cpp:116-117, double pow
+                    const double rough = (double)rtEvalTexture(sc, m.roughness, h.uv).x;
+                    const double r2 = rough * rough;
+                    shiny = (float)((0.5 / (r2 * r2)) - 0.5);
+                }
             }
             // ambient term, added at every node and never scaled (main.cpp:207-211)
             V3 amb;
-            if (m.has_img_texture) amb = ld3(sc.ambient) * 0.1f * rtEvalTexture(sc, m.occlusion, h.uv).x;
+            if (!FAST && m.has_img_texture) amb = ld3(sc.ambient) * 0.1f * rtEvalTexture(sc, m.occlusion, h.uv).x;
             else amb = ld3(sc.ambient) * ld3(m.ambient);
             amb0 = amb * weight;  // level 0: first contribution of the sample, stored below together with the zeros of the misses
 
@@ -1234,7 +1255,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 const float attenuation = RT_COLOR_ATTENUATION(distance);  // :110 (double pow)
                 const V3 diffusion = attenuation * lc * dcol * diffuse;
                 V3 spec = v3s(0.0f);
-                if (aniso) {  // main.cpp:123-139
+                if (!FAST && aniso) {  // main.cpp:123-139
                     const float NdotL = dot(ns, ld), NdotV = dot(ns, view);
                     if (NdotL > 0 && NdotV > 0) {
                         const float HdotT = dot(hv, hT), HdotB = dot(hv, hB), HdotN = dot(hv, ns);
@@ -1579,8 +1600,16 @@ void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues 
     uint32_t slab = 64;
     while (slab < RT_SLAB_MAX && (uint64_t)slab * 16 * waves <= max_inputs) slab <<= 1;
     if (cfg.shade_slab) slab = cfg.shade_slab;
-    if (prof) hipLaunchKernelGGL(k_shade<true>, dim3(rtShadeBlocks(cfg)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(rtShadeBlocks(cfg)), dim3(RT_BLOCK), 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    const dim3 grid(rtShadeBlocks(cfg)), block(RT_BLOCK);
+    // the fast instance first (it fills the general list), then -- only for scenes that hold spheres / cones, BMP-textured
+    // or anisotropic materials -- the general instance over that list.  Both reserve slabs: the queue slack covers two
+    // partly filled slabs per wave and queue (rt_abi.cpp: queueSizes).
+    if (prof) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    if (sc.has_general) {
+        if (prof) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+        else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    }
 }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles) {

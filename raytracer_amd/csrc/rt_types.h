@@ -25,7 +25,9 @@ struct RtNode {
     float mx[3];
     uint32_t b;
 };
+#ifndef RT_LEAF_MAX
 #define RT_LEAF_MAX 4
+#endif
 
 // 4-wide BVH node as the traversal kernels read it: 64 bytes = one cache line = four 16-byte loads per lane.
 // Child boxes are quantised to 8 bits per plane inside the node's frame: plane = origin + q * scale (scale a power
@@ -63,7 +65,7 @@ struct RtNodeP {
 // q3 = (object, rank, prim, 0): what the exact-tie rule needs (see RtTriShade)
 struct RtTriGeom {
     float q0[4], q1[4], q2[4];
-    uint32_t object, rank, prim, _pad;
+    uint32_t object, rank, prim, general;  // general: 0 or RT_ID_GENERAL (ORed into the hit id)
 };
 
 // Per-slot shading attributes, 80 bytes: what Triangle::intersect needs beyond geometry (MeshLoader.h:99-121)
@@ -121,6 +123,9 @@ struct RtSceneDev {
     int32_t n_nodes, n_tris, n_spheres, n_planes, n_lights, n_objects, n_materials;
     int32_t any_ordered;         // shadow rays descend near-first like closest-hit rays (chosen at rt_commit)
     int32_t occluder_cache;      // k_any starts a ray on the triangle that last occluded a ray of its wave (rt_commit)
+    uint64_t plane_general;      // bit k: plane k's material needs the general k_shade
+    int32_t has_general;         // the scene holds primitives that need the general k_shade
+    int32_t _pad0;
 };
 
 // Camera + image constants of the tile loop, precomputed on the host exactly as main.cpp:561-563 does.
@@ -140,6 +145,11 @@ struct RtFrameDev {
 #define RT_ID_SPHERE 0x80000000u  // | sphere index
 #define RT_ID_PLANE 0xC0000000u   // | plane index
 #define RT_ID_KIND_MASK 0xC0000000u
+// A hit whose shading needs the GENERAL k_shade (rt_kernels.hip): a sphere / cone (double-precision uv, Objects.h:80-81),
+// or a triangle / plane whose material samples a BMP map or is anisotropic.  Spheres are recognised by their kind;
+// triangles and planes carry this bit in their id (from the triangle record's 4th word / RtSceneDev::plane_general).
+#define RT_ID_GENERAL 0x10000000u
+#define RT_ID_TRI_MASK 0x0FFFFFFFu            // triangle slot of a triangle id
 
 // ray flags packed above the sample index (28 bits of sample index)
 #define RT_SAMPLE_MASK 0x0FFFFFFFu
@@ -170,6 +180,7 @@ struct RtQueues {
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
     uint32_t *resid;           // rays the packet kernels hand to the per-lane kernels (queue indices)
+    uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap;
 };
@@ -193,6 +204,7 @@ struct RtQueues {
 #define RT_CNT_PROF_PACKET_CLOSEST (73 * RT_CNT_STRIDE)      // 8 x u64 packet statistics of k_packet<closest> (stats build)
 #define RT_CNT_PROF_PACKET_ANY (74 * RT_CNT_STRIDE)          // same for shadow packets
 #define RT_CNT_SHADOW_HOLES (75 * RT_CNT_STRIDE)             // unused slab slots of the shadow queues (not rays)
+#define RT_CNT_GENERAL(d) (75 * RT_CNT_STRIDE + 12 + (d))     // hits of level d left to the general k_shade (d = 0..15)
 #define RT_CNT_ZERO (75 * RT_CNT_STRIDE + 8)                 // shadow rays not emitted because their pending radiance is exactly zero
 #define RT_CNT_UNOCCLUDED (75 * RT_CNT_STRIDE + 4)           // u64: shadow rays that reached their light (stats build)
 #define RT_CNT_RESID_CLOSEST(d) ((76 + (d)) * RT_CNT_STRIDE) // rays of level d handed to the per-lane closest-hit kernel
