@@ -63,20 +63,34 @@ def test_rays_against_reference(scene):
     c3, hits, shadow, st = r.trace_batch(g["rays"], depth=3)
     n = len(g["rays"])
     same = hits["prim"] == g["prim"]
-    assert same.mean() >= 0.999, f"primitive ids agree on {same.mean():.5f}"
     both = same & (g["hit"] == 1)
+    dist_bits = float((bits(hits["distance"][both]) == bits(g["distance"][both])).mean())
+    fields = {k: float(np.isclose(hits[k][both], g[k][both], rtol=1e-5, atol=1e-5, equal_nan=True).all(axis=1).mean())
+              for k in ("intersection", "normal", "normal_shading", "uv", "tangent", "bitangent")}
+    sh = float((shadow[both] == g["shadow"][both]).all(axis=1).mean())
+    cols = []
+    for got, ref in ((c0, g["color_d0"]), (c3, g["color_d3"])):
+        valid = ~np.isnan(ref).any(axis=1)
+        cols.append(float(((np.abs(got - ref).max(axis=1) <= 1e-5) & valid).sum() / n))
+        cols.append(float(np.abs(got - ref)[valid].max()))
+    # achieved values, for profiles/r02_parity_margins.md (pytest -s)
+    print(f"rays_{scene}: prim ids {same.mean():.5f} ({int((~same).sum())} of {n} differ), distance bit-equal {dist_bits:.5f}, "
+          f"hit fields {min(fields.values()):.5f} (worst of {', '.join(fields)}), shadow flags {sh:.5f}, "
+          f"colour depth 0 within 1e-5: {cols[0]:.5f} (max |d| {cols[1]:.2e}), depth 3: {cols[2]:.5f} (max |d| {cols[3]:.2e}), "
+          f"NaN-poisoned in the reference: {int(np.isnan(g['color_d3']).any(axis=1).sum())}")
+    # thresholds = what is achieved on every fixture (r02 margins table) minus a small margin; the rays that differ are
+    # grazing / exact-edge cases where the hit test's outcome hangs on the last bit of a device libm / division result
+    # (round 2, MI355X / ROCm 7.2: ids, distances and Hit fields agree on EVERY fixture ray, colours to 2.4e-7, one shadow
+    # flag of 13 000 differs: profiles/r02_parity_margins.md)
+    assert same.mean() >= 0.9999, f"primitive ids agree on {same.mean():.5f}"
     assert np.array_equal(bits(hits["distance"][both]), bits(g["distance"][both])) or \
         np.allclose(hits["distance"][both], g["distance"][both], rtol=2e-6)
     assert np.array_equal(hits["object"][both], g["object"][both])
     assert np.array_equal(hits["triangle"][both], g["triangle"][both])
-    for k in ("intersection", "normal", "normal_shading", "uv", "tangent", "bitangent"):
-        ok = np.isclose(hits[k][both], g[k][both], rtol=1e-5, atol=1e-5, equal_nan=True).all(axis=1)
-        assert ok.mean() >= 0.999, k
-    assert (shadow[both] == g["shadow"][both]).all(axis=1).mean() >= 0.998
-    for got, ref in ((c0, g["color_d0"]), (c3, g["color_d3"])):
-        valid = ~np.isnan(ref).any(axis=1)
-        close = (np.abs(got - ref).max(axis=1) <= 2e-3) & valid
-        assert close.sum() / n >= 0.995
+    for k, v in fields.items():
+        assert v >= 0.9999, k
+    assert sh >= 0.9995
+    assert cols[0] >= 0.9999 and cols[2] >= 0.9999  # (NaN-poisoned reference colours count as mismatches: none in the fixtures)
 
 
 @pytest.mark.parametrize("name", ["sample_320x210", "competition_256x192", "bunny_160x120", "sample_160x105_spp16",
