@@ -122,7 +122,8 @@ RT_DEV float safeInv(float d) {
 
 struct RtWalk {  // per-lane traversal state
     RtRay r;
-    V3 inv, oi, err;   // 1/d, o/d and the per-axis error bound of a plane distance
+    V3 inv, oi, err;   // 1/d, o/d and the per-axis error bound of a plane distance (set-up only: analytic pre-tests, packets)
+    V3 oiN, oiF;       // o/d with the error bound folded in: oi + err for near planes, oi - err for far planes (node steps)
     float best_t;      // closest hit so far (closest) or the light distance (any-hit)
     uint32_t best_id;
     int best_obj;      // object and reference candidate rank of the best hit: the exact-tie rule needs them
@@ -141,6 +142,8 @@ RT_DEV void rtInitWalk(const RtSceneDev &sc, RtWalk &w, uint32_t root_ref) {
     const float u = 4.76837158e-07f;  // 2^-21
     w.err = v3((fabsf(w.oi.x) + sc.bound * fabsf(w.inv.x)) * u, (fabsf(w.oi.y) + sc.bound * fabsf(w.inv.y)) * u,
                (fabsf(w.oi.z) + sc.bound * fabsf(w.inv.z)) * u);
+    w.oiN = w.oi + w.err;
+    w.oiF = w.oi - w.err;
     w.sp = 0;
     w.cur = sc.n_tris ? root_ref : RT_NODE_DONE;
     w.pend = RT_NODE_DONE;
@@ -197,16 +200,18 @@ RT_DEV void rtNodeStep(const RtSceneDev &sc, RtWalk &w, const RtStack &stk, RtTr
     const uint32_t ln = laneNow();  // the lane's stack column, once for every push / pop of this step
     if (STATS) st.nodes++;
     const V3 m = v3(q0.w * w.inv.x, q3.z * w.inv.y, q3.w * w.inv.z);  // scale / d (scale is a power of two: exact)
-    const float ax = __builtin_fmaf(q0.x, w.inv.x, -w.oi.x), ay = __builtin_fmaf(q0.y, w.inv.y, -w.oi.y),
-                az = __builtin_fmaf(q0.z, w.inv.z, -w.oi.z);
+    // plane distance = fma(q, scale/d, fma(origin, 1/d, -(o/d +- err))): the error bound rides in the second operand
+    // (rounding oi +- err once at set-up stays far inside the bound's 8x margin)
+    const float anx = __builtin_fmaf(q0.x, w.inv.x, -w.oiN.x), any_ = __builtin_fmaf(q0.y, w.inv.y, -w.oiN.y),
+                anz = __builtin_fmaf(q0.z, w.inv.z, -w.oiN.z);
+    const float afx = __builtin_fmaf(q0.x, w.inv.x, -w.oiF.x), afy = __builtin_fmaf(q0.y, w.inv.y, -w.oiF.y),
+                afz = __builtin_fmaf(q0.z, w.inv.z, -w.oiF.z);
     const bool negx = w.inv.x < 0.0f, negy = w.inv.y < 0.0f, negz = w.inv.z < 0.0f;
     const uint32_t lox = __float_as_uint(q2.x), loy = __float_as_uint(q2.y), loz = __float_as_uint(q2.z);
     const uint32_t hix = __float_as_uint(q2.w), hiy = __float_as_uint(q3.x), hiz = __float_as_uint(q3.y);
     const uint32_t nrx = negx ? hix : lox, frx = negx ? lox : hix;
     const uint32_t nry = negy ? hiy : loy, fry = negy ? loy : hiy;
     const uint32_t nrz = negz ? hiz : loz, frz = negz ? loz : hiz;
-    const float anx = ax - w.err.x, afx = ax + w.err.x, any_ = ay - w.err.y, afy = ay + w.err.y, anz = az - w.err.z,
-                afz = az + w.err.z;
     uint32_t ref[4] = {__float_as_uint(q1.x), __float_as_uint(q1.y), __float_as_uint(q1.z), __float_as_uint(q1.w)};
     uint32_t key[4];
 #pragma unroll
@@ -502,7 +507,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     uint32_t ray_i = 0, sample = 0;
     RtWalk w;
     w.r = RtRay{v3s(0.0f), v3s(0.0f)};
-    w.inv = w.oi = w.err = v3s(0.0f);
+    w.inv = w.oi = w.err = w.oiN = w.oiF = v3s(0.0f);
     w.best_t = INFINITY;
     w.best_id = RT_ID_MISS;
     w.best_obj = 0x7FFFFFFF;
@@ -1216,7 +1221,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             }
         }
 
-        if (level > 0) accumulateRuns(q.accum, active, sample, amb0);  // ambient term of the hit (levels >= 1)
+        // ambient term of the hit (levels >= 1); an exactly zero term (materials without ambient colour) adds nothing
+        if (level > 0) accumulateRuns(q.accum, active && !(amb0.x == 0.0f && amb0.y == 0.0f && amb0.z == 0.0f), sample, amb0);
         if (level == 0 && active) {
             // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
             // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.

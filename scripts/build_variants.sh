@@ -7,7 +7,7 @@ build_one() {
   name=${1%%:*}; defs=${1#*:}
   d=build_variants/obj_$name; mkdir -p $d
   for f in rt_kernels.hip rt_abi.cpp rt_bvh.cpp; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $defs -Iraytracer_amd/csrc -c raytracer_amd/csrc/$f -o $d/${f%.*}.o
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $defs -Iraytracer_amd/csrc -c raytracer_amd/csrc/$f -o $d/${f%.*}.o
   done
   hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o build_variants/$name.so $d/rt_kernels.o $d/rt_abi.o $d/rt_bvh.o
   rm -rf $d

@@ -3,7 +3,7 @@
 usage: python scripts/kernel_resources.py [extra hipcc flags...]"""
 import os, re, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-c",
        "rt_kernels.hip", "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 out = subprocess.run(cmd, cwd=os.path.join(REPO, "raytracer_amd", "csrc"), capture_output=True, text=True).stderr
 cur = None
