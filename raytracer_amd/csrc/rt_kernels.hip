@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     const int nlights = sc.n_lights;
     uint32_t culled = 0, shaded = 0, zero = 0;
     // PROF build: shader clocks per section, summed over waves: [0] loads + hit reconstruction, [1] material, light
-    // culling, textures, ambient, bounce set-up, [2] (unused since the slabs), [3] shadow-ray emission,
+    // culling, textures, ambient, bounce set-up, [2] the scan for hits, [3] direct light + shadow-ray emission,
     // [4] next-level emission, [5] iterations
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}, tp = PROF ? __builtin_amdgcn_s_memtime() : 0ull, tn = 0;
 #define RT_PROF_MARK(k) if (PROF) { tn = __builtin_amdgcn_s_memtime(); prof[k] += tn - tp; tp = tn; }
@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n);
             }
         }
+        RT_PROF_MARK(2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t takeN = min(count, 64u);
@@ -1246,7 +1247,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             acc[2] = rtToFixed(amb0.z);
         }
         RT_PROF_MARK(1)
-        RT_PROF_MARK(2)
         // ---- direct light: per light the pending radiance (main.cpp:102-145) rides on its shadow ray ----
         // A shadow ray whose pending radiance is exactly zero cannot change the image: whether it reaches the light or
         // not, zero is added.  The reference still casts it (is_shadowed runs before the colour is computed,

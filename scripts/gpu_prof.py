@@ -20,7 +20,7 @@ for name, rays in (("prof_closest", st["rays_closest"]), ("prof_any", st["rays_s
 p = st["prof_shade"]
 tot = sum(p[:5])
 print("prof_shade hits", st["hits_shaded"], "iterations", p[5], "cycles/iteration %.0f" % (tot / max(p[5], 1)))
-for k, name in enumerate(("load+reconstruct", "material/cull/texture/ambient/bounce", "reservation", "shadow emission", "next-level emission")):
+for k, name in enumerate(("load+reconstruct", "material/cull/texture/ambient/bounce", "scan for hits", "direct light + shadow emission", "next-level emission")):
     print("  %-40s %5.1f%%  %.0f cycles/iteration" % (name, 100 * p[k] / tot, p[k] / max(p[5], 1)))
 for name in ("prof_packet_closest", "prof_packet_any"):
     p = st[name]
