@@ -1066,6 +1066,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     // wave leaves unused at the end is marked as holes (shadow: w = RT_SHADOW_HOLE; rays: RT_FLAG_INVALID), which the
     // trace kernels skip; holes are counted so that the ray statistics stay exact.
     uint32_t curv = 0, endv = 0, holesS = 0, holesR = 0;
+    uint32_t gcur = 0, gend = 0;  // the wave's slab of the general list (wave-uniform)
     const uint32_t slabS = slab, slabR = max(slab, 128u);  // one iteration emits at most 64 shadow rays per light, 128 rays
     const int buf = level & 1, nbuf = buf ^ 1;
     const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(level)], q.ray_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
@@ -1097,9 +1098,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             const uint32_t j = scan + lane;
             const bool valid = j < segEnd;
             // FAST: entry j of the level's ray queue; GENERAL: entry j of the list the fast instance left (all hits)
-            const uint32_t qi = GENERAL ? (valid ? q.general[j] : 0u) : j;
+            const uint32_t qi = GENERAL ? (valid ? q.general[j] : RT_GENERAL_HOLE) : j;
             const uint32_t hid = GENERAL ? 0u : __float_as_uint(q.hits[valid ? j : 0].y);
-            bool hit = valid && (GENERAL || hid != RT_ID_MISS);
+            bool hit = valid && (GENERAL ? qi != RT_GENERAL_HOLE : hid != RT_ID_MISS);
             if (!GENERAL && level == 0 && valid && !hit) {  // miss, or slot outside the image: the sample's first and only level-0 entry
                 long long *acc = q.accum + 3ull * (__float_as_uint(q.rayB[buf][j].w) & RT_SAMPLE_MASK);
                 acc[0] = 0;
@@ -1109,10 +1110,23 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             if (!GENERAL) {  // what this instance cannot shade goes to the general one's list
                 const bool gen = hit && ((hid & RT_ID_KIND_MASK) == RT_ID_SPHERE || (hid & RT_ID_GENERAL));
                 const unsigned long long gm = __ballot(gen);
-                if (gm) {  // wave-uniform, rare
-                    const uint32_t gbase = waveReserve(q.counters + RT_CNT_GENERAL(level), (uint32_t)__popcll(gm));
-                    if (gen) q.general[gbase + maskRankBelow(gm)] = j;
-                    if (gen) hit = false;
+                if (gm) {  // wave-uniform.  List slots come from a wave-private slab too: in a scene of spheres nearly every
+                           // scan step appends, and one returning atomic per step on ONE counter serialises the chip
+                    const uint32_t c = (uint32_t)__popcll(gm), rank = maskRankBelow(gm), room = gend - gcur;
+                    uint32_t slot = gcur + rank;
+                    if (c > room) {  // the slab is used up to its last slot, the rest opens the next one
+                        const uint32_t nbase = waveReserve(q.counters + RT_CNT_GENERAL(level), slabR);
+                        if (rank >= room) slot = nbase + (rank - room);
+                        gcur = nbase + (c - room);
+                        gend = nbase + slabR;
+                    } else {
+                        gcur += c;
+                    }
+                    if (gen) {
+                        if (slot < q.ray_cap) q.general[slot] = j;
+                        else atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
+                        hit = false;
+                    }
                 }
             }
             const unsigned long long hm = __ballot(hit);
@@ -1388,6 +1402,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         for (uint32_t sl = cur + lane; sl < end; sl += 64) q.rayB[nbuf][sl] = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
         if (lane == 0 && end > cur) holesR += end - cur;
     }
+    if (!GENERAL)  // unused slots of the general list's slab: holes the general instance's scan skips
+        for (uint32_t sl = gcur + lane; sl < min(gend, q.ray_cap); sl += 64) q.general[sl] = RT_GENERAL_HOLE;
     if (PROF && lane == 0) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + RT_CNT_PROF_SHADE);
         for (int k = 0; k < 6; k++) atomicAdd(dst + k, prof[k]);

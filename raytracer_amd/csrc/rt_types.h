@@ -150,6 +150,7 @@ struct RtFrameDev {
 // triangles and planes carry this bit in their id (from the triangle record's 4th word / RtSceneDev::plane_general).
 #define RT_ID_GENERAL 0x10000000u
 #define RT_ID_TRI_MASK 0x0FFFFFFFu            // triangle slot of a triangle id
+#define RT_GENERAL_HOLE 0xFFFFFFFFu  // unused slot of a wave's slab of the general list (RtQueues::general)
 
 // ray flags packed above the sample index (28 bits of sample index)
 #define RT_SAMPLE_MASK 0x0FFFFFFFu
