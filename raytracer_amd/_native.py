@@ -172,5 +172,6 @@ def host_lib(lazy=False):
     lib.rth_mesh_create.restype = VP
     lib.rth_mesh_create.argtypes = [C.c_char_p, C.c_float, C.c_float, C.c_float, VP]
     lib.rth_scene_upload.argtypes = [VP, VP]
+    lib.rth_scan_float.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     _host = lib
     return lib

@@ -13,12 +13,73 @@
 // acceleration structure is built once over the whole flattened scene by rt_commit().
 // A missing file is a hard error here (the reference prints and carries on into UB).
 #pragma once
+#include <cstdint>
 #include <cstdio>
-#include <fstream>
+#include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
 #include "Object.h"
+
+// %f of the .obj scanner: what strtof returns, computed without it for the common case.  A decimal with at most 19
+// significant digits is m * 10^e with m exact in a u64; for m <= 2^53 and |e| <= 22 one double multiplication or
+// division is correctly rounded (both operands exact), and rounding that double to float equals rounding the decimal
+// itself unless the double sits exactly on a float rounding midpoint (low 29 mantissa bits == 2^28) -- then, and for
+// everything unusual ('+', hex, inf / nan, more digits, big exponents, float denormals / overflow), the caller falls
+// back to strtof.  Returns false for "not handled here"; on success *end is where strtof would stop.
+inline bool objFastFloat(const char *p, const char **end, float *out) {
+    static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                      1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *s = p;
+    const bool neg = *s == '-';
+    if (neg) ++s;
+    uint64_t m = 0;
+    int nd = 0, e10 = 0;
+    bool any = false;
+    for (; *s >= '0' && *s <= '9'; ++s, any = true) {
+        if (nd >= 19) return false;
+        m = m * 10 + (uint64_t)(*s - '0');
+        if (m) nd++;
+    }
+    if (*s == '.') {
+        ++s;
+        for (; *s >= '0' && *s <= '9'; ++s, any = true) {
+            if (nd >= 19) return false;
+            m = m * 10 + (uint64_t)(*s - '0');
+            if (m) nd++;
+            e10--;
+        }
+    }
+    if (!any) return false;
+    if (*s == 'x' || *s == 'X') return false;  // "0x...": strtof reads hexadecimal
+    if (*s == 'e' || *s == 'E') {
+        const char *t = s + 1;
+        const bool eneg = *t == '-';
+        if (*t == '-' || *t == '+') ++t;
+        if (*t >= '0' && *t <= '9') {  // (no digits: the 'e' is not part of the number)
+            int ev = 0;
+            for (; *t >= '0' && *t <= '9'; ++t)
+                if (ev < 10000) ev = ev * 10 + (*t - '0');
+            e10 += eneg ? -ev : ev;
+            s = t;
+        }
+    }
+    double d;
+    if (m == 0) {
+        d = 0.0;
+    } else {
+        if (m > (1ull << 53) || e10 < -22 || e10 > 22) return false;
+        d = e10 < 0 ? (double)m / kPow10[-e10] : (double)m * kPow10[e10];
+        if (!(d >= 1.17549435e-38 && d <= 3.40282347e+38)) return false;  // float denormal or overflow: strtof
+        uint64_t bits;
+        memcpy(&bits, &d, 8);
+        if ((bits & 0x1FFFFFFFull) == 0x10000000ull) return false;      // on a float midpoint: strtof decides
+    }
+    *out = (float)(neg ? -d : d);
+    *end = s;
+    return true;
+}
 
 struct Triangle {
     glm::vec3 vertexA, vertexB, vertexC;
@@ -59,28 +120,82 @@ class MeshLoader : public Object {
 public:
     MeshLoader(const std::string &filename, glm::vec3 translation, bool hasMaterial, Material m = Material()) {
         if (hasMaterial) setMaterial(m);
-        std::ifstream file(filename);
-        if (!file.is_open()) throw std::runtime_error("MeshLoader: could not open " + filename);
+        // The whole file is read at once and scanned in place.  The reference parses every line with sscanf
+        // (MeshLoader.h:323-371); sscanf on a string first measures it and sets up a stream, which made the parse 3x
+        // slower than the conversions themselves.  The scanner below performs the same conversions (strtof / strtol
+        // are what %f / %d call) with sscanf's matching rules: a literal must match exactly, white space in the format
+        // skips any white space, %f skips leading white space, the first failure ends the line and leaves the
+        // remaining targets as they were.
+        std::string buf;
+        {
+            FILE *fp = fopen(filename.c_str(), "rb");
+            if (!fp) throw std::runtime_error("MeshLoader: could not open " + filename);
+            char chunk[1 << 16];
+            size_t got;
+            while ((got = fread(chunk, 1, sizeof chunk, fp)) > 0) buf.append(chunk, got);
+            fclose(fp);
+        }
         minBounds = glm::vec3(INFINITY);
         maxBounds = glm::vec3(-INFINITY);
         // scan targets live across lines on purpose (stale-index quirk)
         float x = 0, y = 0, z = 0, nx = 0, ny = 0, nz = 0, tx = 0, ty = 0, tz = 0;
         int smoothShading = 0;
         bool sawTexture = false;
-        std::string line;
-        while (std::getline(file, line)) {
-            const char c0 = line.size() > 0 ? line[0] : '\0';
-            const char c1 = line.size() > 1 ? line[1] : '\0';
-            const char *s = line.c_str();
+        struct Scan {
+            const char *p;
+            bool ok = true;
+            static bool space(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+            void ws() { while (space(*p)) ++p; }
+            Scan &lit(char c) {   // an ordinary character of the format
+                if (ok) { if (*p == c) ++p; else ok = false; }
+                return *this;
+            }
+            Scan &sp() {          // white space in the format
+                if (ok) ws();
+                return *this;
+            }
+            Scan &f(float &out) {  // %f
+                if (ok) {
+                    ws();
+                    const char *e;
+                    float v;
+                    if (!objFastFloat(p, &e, &v)) {
+                        char *e2;
+                        v = strtof(p, &e2);
+                        e = e2;
+                    }
+                    if (e == p) ok = false; else { out = v; p = e; }
+                }
+                return *this;
+            }
+            Scan &d(int &out) {    // %d
+                if (ok) {
+                    ws();
+                    char *e;
+                    const long v = strtol(p, &e, 10);
+                    if (e == p) ok = false; else { out = (int)v; p = e; }
+                }
+                return *this;
+            }
+        };
+        char *cur = buf.empty() ? nullptr : &buf[0], *const end = cur + buf.size();
+        while (cur && cur < end) {  // std::getline's lines: up to '\n' (a last line without one counts)
+            char *nl = (char *)memchr(cur, '\n', (size_t)(end - cur));
+            char *const next = nl ? nl + 1 : end;
+            if (nl) *nl = '\0';  // (end itself is the string's terminator)
+            const size_t len = (size_t)((nl ? nl : end) - cur);
+            const char c0 = len > 0 ? cur[0] : '\0';
+            const char c1 = len > 1 ? cur[1] : '\0';
+            Scan sc{cur};
             if (c1 == 'n') {
-                sscanf(s, "vn %f %f %f", &x, &y, &z);
+                sc.lit('v').lit('n').sp().f(x).sp().f(y).sp().f(z);  // "vn %f %f %f"
                 normals.emplace_back(x + translation.x, y + translation.y, z + translation.z);
             } else if (c1 == 't') {
-                sscanf(s, "vt %f %f", &x, &y);
+                sc.lit('v').lit('t').sp().f(x).sp().f(y);            // "vt %f %f"
                 textureCoords.emplace_back(x + translation.x, y + translation.y);
                 sawTexture = true;
             } else if (c0 == 'v') {
-                sscanf(s, "v %f %f %f", &x, &y, &z);
+                sc.lit('v').sp().f(x).sp().f(y).sp().f(z);           // "v %f %f %f"
                 glm::vec3 p(x + translation.x, y + translation.y, z + translation.z);
                 vertices.push_back(p);
                 for (int k = 0; k < 3; k++) {
@@ -88,26 +203,29 @@ public:
                     maxBounds[k] = std::fmax(maxBounds[k], p[k]);
                 }
             } else if (c0 == 's') {
-                sscanf(s, "s %d", &smoothShading);
+                sc.lit('s').sp().d(smoothShading);                   // "s %d"
             } else if (c0 == 'f') {
                 if (smoothShading == 0) {
-                    sscanf(s, "f %f %f %f", &x, &y, &z);
+                    sc.lit('f').sp().f(x).sp().f(y).sp().f(z);       // "f %f %f %f"
                     addTriangle(at(vertices, x, "vertex", filename), at(vertices, y, "vertex", filename),
                                 at(vertices, z, "vertex", filename));
-                } else if (sawTexture) {
-                    sscanf(s, "f %f/%f/%f %f/%f/%f %f/%f/%f", &x, &tx, &nx, &y, &ty, &ny, &z, &tz, &nz);
+                } else if (sawTexture) {                             // "f %f/%f/%f %f/%f/%f %f/%f/%f"
+                    sc.lit('f').sp().f(x).lit('/').f(tx).lit('/').f(nx).sp().f(y).lit('/').f(ty).lit('/').f(ny).sp()
+                        .f(z).lit('/').f(tz).lit('/').f(nz);
                     addTriangle(at(vertices, x, "vertex", filename), at(vertices, y, "vertex", filename),
                                 at(vertices, z, "vertex", filename), at(normals, nx, "normal", filename),
                                 at(normals, ny, "normal", filename), at(normals, nz, "normal", filename),
                                 at(textureCoords, tx, "uv", filename), at(textureCoords, ty, "uv", filename),
                                 at(textureCoords, tz, "uv", filename));
-                } else {
-                    sscanf(s, "f %f//%f %f//%f %f//%f", &x, &nx, &y, &ny, &z, &nz);
+                } else {                                             // "f %f//%f %f//%f %f//%f"
+                    sc.lit('f').sp().f(x).lit('/').lit('/').f(nx).sp().f(y).lit('/').lit('/').f(ny).sp()
+                        .f(z).lit('/').lit('/').f(nz);
                     addTriangle(at(vertices, x, "vertex", filename), at(vertices, y, "vertex", filename),
                                 at(vertices, z, "vertex", filename), at(normals, nx, "normal", filename),
                                 at(normals, ny, "normal", filename), at(normals, nz, "normal", filename));
                 }
             }
+            cur = next;
         }
     }
 

@@ -31,8 +31,9 @@ void addMesh(const std::string &dir, const char *file, glm::vec3 at, const Mater
     lastIngest().meshes++;
 }
 
-// Several meshes at once: .obj parsing is the largest part of loading the competition scene (16 files, ~160 ms of
-// sscanf on one core -- profiles/r02_ingest.md), the files are independent, so each is parsed on a thread of its own;
+// Several meshes at once: .obj parsing is the largest part of loading the competition scene (16 files: ~160 ms of sscanf
+// on one core, ~38 ms with MeshLoader.h's in-place scanner -- profiles/r02_ingest.md); the files are independent, so each
+// is parsed on a thread of its own;
 // the objects enter `objects` in the given order (the first object wins distance ties, main.cpp:67).
 struct MeshJob { std::string path; glm::vec3 at; const Material *m; };
 void addMeshes(const std::vector<MeshJob> &jobs) {

@@ -134,6 +134,23 @@ void *rth_mesh_create(const char *path, float tx, float ty, float tz, int64_t *c
 }
 
 // flatten -> rt_set_* -> rt_commit on an existing context
+// test hook: the .obj scanner's %f on one string: value, characters consumed (0 = no conversion), and whether the
+// fast path (not strtof) produced it
+int rth_scan_float(const char *text, float *value, int32_t *consumed, int32_t *fast) {
+    const char *e = text;
+    float v = 0.0f;
+    const bool f = objFastFloat(text, &e, &v);
+    if (!f) {
+        char *e2;
+        v = strtof(text, &e2);
+        e = e2;
+    }
+    *value = v;
+    *consumed = (int32_t)(e - text);
+    *fast = f ? 1 : 0;
+    return 0;
+}
+
 int rth_scene_upload(void *h, rt_context *ctx) {
     try {
         HostScene *hs = (HostScene *)h;
