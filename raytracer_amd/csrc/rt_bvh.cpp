@@ -302,6 +302,12 @@ struct Collapser {
             kids[pick + 1] = bn[open].a + 1;
             nk++;
         }
+        // Child slots in order of surface, smallest first.  Closest-hit walks sort the hit children by distance, so the
+        // slot order means nothing to them; any-hit walks enter the first hit child and pop the others in slot order,
+        // and the small boxes are where the geometry is dense: an occluded shadow ray finds its occluder sooner
+        // (k_any 132 -> 128 ms on the 4K competition frame; largest first: 138).
+        for (int i = 1; i < nk; i++)
+            for (int j = i; j > 0 && halfArea(bn[kids[j]]) < halfArea(bn[kids[j - 1]]); j--) std::swap(kids[j], kids[j - 1]);
         maxDepth = std::max(maxDepth, depth);
         maxStack = std::max(maxStack, pending + nk - 1);
         // frame = union of the children's (padded) boxes
