@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--cpu-sample", default="480x360")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gather even with one rank (rehearses the RCCL path on a 1-GPU box)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N ranks on ONE card: every rank renders on cuda:0 and the gather goes through host tensors and gloo "
+                         "(RCCL wants one GPU per rank).  Checks the control flow of the N > 1 path on a 1-GPU box, not its speed")
     a = ap.parse_args()
 
     import numpy as np
@@ -89,19 +92,25 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
     dist = None
+    if a.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or a.force_dist
     if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     scene = FlatScene.builtin(a.scene)
     r = Renderer(local_rank).set_scene(scene)
     W, H = a.width, a.height
     from raytracer_amd.dist import DistributedFrame, tile_counts
     n_tiles = tile_counts(W, H, 0, 1)[1]
-    df = DistributedFrame(r, W, H, rank, world, dev, dist, force_collective=a.force_dist)   # tile-major device buffers owned by torch
+    df = DistributedFrame(r, W, H, rank, world, dev, dist, force_collective=a.force_dist,
+                          stage_host=a.rehearse_gloo)   # tile-major device buffers owned by torch
     # one explicit stream for render, gather and assembly: torch's legacy default stream has handle 0, which the C ABI reads
     # as "the context's own stream" -- the RCCL gather (ordered against torch's CURRENT stream) would then not be ordered
     # against the render / assembly kernels
@@ -132,7 +141,7 @@ def main():
         prim += st["primary_samples"]
     sync()
     dt = time.perf_counter() - t0
-    tot = torch.tensor([dt, float(rays), float(prim), float(zero)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([dt, float(rays), float(prim), float(zero)], dtype=torch.float64, device="cpu" if a.rehearse_gloo else dev)
     if use_dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -156,10 +165,13 @@ def main():
                      "reference_defined_mrays_per_s": (rays_all + zero_all) / dt / 1e6},
             "ms_per_frame": dt / max(a.steps, 1) * 1e3, "bvh": {"nodes": st["bvh_nodes"], "depth": st["bvh_depth"]},
         }
-    if rank == 0 and not a.no_roofline:
-        from raytracer_amd._native import kernel_source_hash
+    if not a.no_roofline:
+        # EVERY rank renders the two instrumented frames: a frame ends in a collective (the gather), so rank 0 alone
+        # would wait for peers that have moved on.  The figures reported are rank 0's (its share of the tiles).
         timed = frame(collect=2)       # per-kernel-class HIP-event timing on the launch stream
         counted = frame(collect=1)     # in-kernel record counters (stats build of the same kernels, counts only)
+    if rank == 0 and not a.no_roofline:
+        from raytracer_amd._native import kernel_source_hash
         pc, pa = counted["prof_packet_closest"], counted["prof_packet_any"]
         # records fetched, counted in-kernel in THIS run: (ms, launches, node steps, triangle steps, rays)
         kinds = {

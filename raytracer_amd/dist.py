@@ -46,10 +46,12 @@ def gather_tiles(local, rank, world, dist=None, force_collective=False):
 class DistributedFrame:
     """One rank's share of a frame on its GPU: render own tiles -> gather -> (rank 0) assemble the image."""
 
-    def __init__(self, renderer, width, height, rank, world, device, dist=None, force_collective=False):
+    def __init__(self, renderer, width, height, rank, world, device, dist=None, force_collective=False, stage_host=False):
         import torch
         self.r, self.W, self.H, self.rank, self.world, self.dist = renderer, width, height, rank, world, dist
         self.force_collective = force_collective  # run the gather even with one rank (rehearsal of the RCCL path)
+        # rehearsal of N ranks on ONE card (RCCL wants a GPU per rank): the gather goes through host tensors and gloo
+        self.stage_host = stage_host
         self.per = tiles_per_rank(width, height, world)
         self.device = device
         self.t8 = torch.zeros(self.per, TILE_PIXELS, 3, dtype=torch.uint8, device=device)
@@ -80,6 +82,16 @@ class DistributedFrame:
                                         stream=stream, **kw)   # (complete when the call returns)
         if not self.collective:
             g8, gp = self.t8, self.tp
+        elif self.stage_host:
+            torch.cuda.synchronize(self.device)
+            for loc, dst in ((self.t8, getattr(self, "g8", None)), (self.tp, getattr(self, "gp", None))):
+                h = loc.cpu()
+                hg = torch.empty((self.world,) + tuple(h.shape), dtype=h.dtype) if self.rank == 0 else None
+                self.dist.gather(h, list(hg.unbind(0)) if self.rank == 0 else None, dst=0)
+                if self.rank == 0:
+                    dst.copy_(hg)
+            g8, gp = (self.g8, self.gp) if self.rank == 0 else (None, None)
+            torch.cuda.synchronize(self.device)
         else:
             self.dist.gather(self.t8, list(self.g8.unbind(0)) if self.rank == 0 else None, dst=0)
             self.dist.gather(self.tp, list(self.gp.unbind(0)) if self.rank == 0 else None, dst=0)

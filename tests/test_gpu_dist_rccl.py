@@ -32,3 +32,24 @@ def test_bench_under_torchrun_with_rccl_gather():
     assert plain.returncode == 0, plain.stderr[-2000:]
     p = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
     assert p["rays_per_primary"] == d["rays_per_primary"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow_on_one_card():
+    """bench.py as the driver launches it for N = 2, roofline leg included, with both ranks on cuda:0 and the gather
+    through gloo (--rehearse-gloo): every rank must reach every collective (a rank-0-only frame would hang here), the line
+    must report n_gpus 2 and the two shares must add up to the single-process frame's rays."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "2", "--warmup", "1", "--scene", "sample", "--width", "320", "--height", "208", "--spp", "4", "--no-cpu"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-gloo"] + common
+    out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "tiles%2" and "roofline" in d and "kernel_ms" in d
+    plain = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--no-roofline"] + common,
+                           cwd=REPO, env=env, capture_output=True, text=True, timeout=240)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    p = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rays"]["traced_per_frame"] == p["rays"]["traced_per_frame"]
+    assert d["rays"]["reference_per_frame"] == p["rays"]["reference_per_frame"]
