@@ -156,7 +156,9 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / max(a.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "reference scene assets (meshes/*.obj), synthetic camera samples",
             "config": {"workload": f"{a.scene} scene {W}x{H} @{a.spp}spp depth {a.depth}", "triangles": scene.n_triangles,
-                       "tiles": n_tiles, "parallelism": f"tiles%{world}", "chunk_samples": a.chunk or (1 << 26)},
+                       "tiles": n_tiles, "parallelism": f"tiles%{world}",
+                       "chunk_samples": a.chunk or "adaptive (fan-out observed on the scene; DESIGN.md 2)",
+                       "chunks_per_frame": st["chunks"], "chunk_retries_last_frame": st["chunk_retries"]},
             "primary_samples_per_s": prim_all / dt, "rays_per_primary": rays_all / max(prim_all, 1.0),
             # `value` counts the queries that were TRACED.  The reference casts more: shadow rays whose pending radiance is
             # exactly zero (main.cpp:172 with refraction 1) are not emitted here (bit-identical image; rt_stats.shadow_zero)

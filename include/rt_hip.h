@@ -132,6 +132,9 @@ typedef struct rt_stats {
     uint64_t shadow_zero;       /* shadow rays the reference casts (Ray ctor at main.cpp:49) that are NOT traced here because their
                                    pending radiance is exactly zero (e.g. main.cpp:172 with refraction 1): rays_shadow + shadow_zero
                                    is the reference's shadow-ray count */
+    uint64_t chunks;            /* chunks of whole tiles the frame was rendered in (including repeated ones) */
+    uint64_t chunk_retries;     /* chunks whose queues, sized from the fan-out seen so far, overflowed and that were rendered
+                                   again with worst-case queues (results are those of the repeat; 0 in steady state) */
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

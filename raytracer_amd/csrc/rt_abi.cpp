@@ -106,11 +106,17 @@ struct rt_context {
     RtSceneDev dev{};
     // wavefront workspace (sized for one chunk, reused across calls)
     size_t ws_samples = 0, ws_bytes = 0;
+    // Fan-out observed on this scene: queue entries per primary sample at the fullest level, maximum over the chunks
+    // rendered since rt_commit (rays; shadow rays over all lights), and the deepest bounce budget it was seen at.
+    // Chunks are sized from it once it exists (renderTiles); reset by rt_commit.
+    bool obs_valid = false;
+    double obs_ray = 0.0, obs_sh = 0.0;
+    int obs_depth = -1;
     DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shC;
     DevBuf<float> d_rayR[2];
     DevBuf<float2> d_hits;
     DevBuf<long long> d_accum;
-    DevBuf<uint32_t> d_counters, d_chunk_counters;
+    DevBuf<uint32_t> d_counters;
     RtQueues q{};
     // the library's static scratch on this context's device (rt_render_tiles_static); resolved at rt_create
     void *scratch = nullptr;
@@ -135,27 +141,41 @@ struct QueueSizes {
     size_t ray_cap, sh_cap, bytes;
     bool fits32;
 };
-QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl) {
+// ray_fan / sh_fan: queue entries per primary sample at the fullest level (rays; shadow rays over all lights)
+QueueSizes queueSizes(const rt_context *ctx, size_t samples, double ray_fan, double sh_fan, int nl) {
     QueueSizes z;
     const size_t waves = (size_t)rtShadeWaves(ctx->cfg);
+    const size_t rays = (size_t)std::ceil((double)samples * ray_fan), shadows = (size_t)std::ceil((double)samples * sh_fan);
     // (x 2: the fast and the general instance of k_shade both reserve slabs)
-    z.ray_cap = samples * fanout + 2 * waves * RT_SLAB_MAX + samples * fanout / 64 + 128;
-    z.sh_cap = samples * fanout * nl + 2 * waves * nl * RT_SLAB_MAX;
+    z.ray_cap = rays + 2 * waves * RT_SLAB_MAX + rays / 64 + 128;
+    z.sh_cap = shadows + 2 * waves * nl * RT_SLAB_MAX;
     z.fits32 = z.ray_cap < (1ull << 32) && z.sh_cap < (1ull << 32);
     z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + z.sh_cap * 32 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
     return z;
+}
+QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl) {  // worst case
+    return queueSizes(ctx, samples, (double)fanout, (double)fanout * nl, nl);
 }
 
 // rays of the deepest level per primary sample, worst case: every hit spawns a reflection/refraction pair (main.cpp:148-205)
 int worstFanout(int max_depth) { return 1 << std::min(std::max(max_depth, 0), 15); }
 
+int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z);
 int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights) {
-    const QueueSizes z = queueSizes(ctx, samples, worstFanout(max_depth), std::max(n_lights, 1));
+    return ensureWorkspace(ctx, samples, queueSizes(ctx, samples, worstFanout(max_depth), std::max(n_lights, 1)));
+}
+int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
     if (!z.fits32) return fail("chunk too large: queue capacity exceeds 2^32 entries");
     if (samples <= ctx->ws_samples && z.ray_cap <= ctx->q.ray_cap && z.sh_cap <= ctx->q.shadow_cap) return 0;
     // grow: capacities only ever go up (a later call with fewer samples but more bounces keeps the larger of each)
     samples = std::max(samples, ctx->ws_samples);
-    const size_t ray_cap = std::max<size_t>(z.ray_cap, ctx->q.ray_cap), sh_cap = std::max<size_t>(z.sh_cap, ctx->q.shadow_cap);
+    // a queue that must grow grows by an eighth more than asked (capped below 2^32): the fan-out a scene shows moves by a
+    // few per cent from frame to frame, and every growth is a hipFree + hipMalloc of tens of GB
+    auto grown = [](size_t want, size_t have) -> size_t {
+        if (want <= have) return have;
+        return have ? std::min<size_t>(want + want / 8, 0xFFFFFFFEull) : want;
+    };
+    const size_t ray_cap = grown(z.ray_cap, ctx->q.ray_cap), sh_cap = grown(z.sh_cap, ctx->q.shadow_cap);
     // DevBuf::alloc frees before it allocates: after a failed grow some buffers are new, some are gone.  The
     // workspace is then declared empty (sizes 0, queue pointers null), so that no later call takes the early return
     // above and launches kernels on freed memory; the next call allocates from scratch.
@@ -336,32 +356,8 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     int64_t n_local = 0, n_total = 0;
     rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, &n_total);
     const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
-    size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : (size_t)1 << 26;
-    chunk_samples = std::min<size_t>(chunk_samples, RT_SAMPLE_MASK);
-    if (p->chunk_samples <= 0) {
-        // default chunk: 64 Mi samples, halved until the queues' worst case fits 32-bit indices and 7/8 of the memory
-        // that is FREE on this device (torch, RCCL or other contexts may hold part of the HBM) plus what this
-        // context's workspace already holds
-        size_t free_b = 0, total_b = 0;
-        HIPOK(hipMemGetInfo(&free_b, &total_b));
-        const size_t budget = (free_b + ctx->ws_bytes) / 8 * 7;
-        const int fo = worstFanout(p->max_depth), nl = std::max<int>(1, (int)ctx->lights.size());
-        while (chunk_samples > per_tile) {
-            const QueueSizes z = queueSizes(ctx, chunk_samples, fo, nl);
-            if (z.fits32 && z.bytes <= budget) break;
-            chunk_samples /= 2;
-        }
-    }
-    size_t chunk_tiles = std::max<size_t>(1, chunk_samples / per_tile);
-    chunk_tiles = std::min<size_t>(chunk_tiles, std::max<int64_t>(n_local, 1));
-    if (n_local > 0) {  // equal chunks: no small straggler at the end of the frame
-        const size_t nc = ((size_t)n_local + chunk_tiles - 1) / chunk_tiles;
-        chunk_tiles = ((size_t)n_local + nc - 1) / nc;
-    }
-    if (chunk_tiles * per_tile > RT_SAMPLE_MASK) return fail("spp too large for one tile per chunk");
-    if (ensureWorkspace(ctx, chunk_tiles * per_tile, p->max_depth, (int)ctx->lights.size())) return 1;
-    const size_t n_chunks = n_local ? (size_t)((n_local + chunk_tiles - 1) / chunk_tiles) : 0;
-    if (ctx->d_chunk_counters.alloc(std::max<size_t>(n_chunks, 1) * RT_CNT_WORDS)) return 1;
+    if (per_tile > RT_SAMPLE_MASK) return fail("spp too large for one tile per chunk");
+    const int fo = worstFanout(p->max_depth), nl = std::max<int>(1, (int)ctx->lights.size());
 
     RtLaunchCfg cfg = ctx->cfg;
     cfg.stream = stream;
@@ -378,20 +374,92 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     HIPOK(hipEventCreate(&ev1));
     HIPOK(hipEventRecord(ev0, stream));
     if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
-    for (size_t c = 0; c < n_chunks; c++) {
-        const uint32_t tile0 = (uint32_t)(c * chunk_tiles);
-        const uint32_t ntiles = (uint32_t)std::min<size_t>(chunk_tiles, (size_t)n_local - tile0);
+    // Chunks of whole tiles.  Large chunks are faster (deep levels hold few rays, and every launch ends with its longest
+    // ray: 8 chunks of 64 Mi samples cost 7 % more than 2 of 265 M on the 4K / 64 spp frame), but a chunk's queues must
+    // hold its fullest level, and the WORST case (every hit spawns a pair, every light faces every hit: 2^depth rays and
+    // 2^depth x lights shadow rays per sample) is 5-20 x what scenes produce.  So: the first chunk after rt_commit is
+    // sized for the worst case (64 Mi samples, halved until it fits 32-bit indices and the free memory); its counters
+    // give the fan-out this scene really has, and later chunks -- of this frame and of the following ones -- are sized
+    // for 1.5 x the largest fan-out seen so far.  A chunk that overflows its queues after all (the kernels drop and
+    // count what does not fit; nothing is written out of bounds) is rendered again at worst-case size: outputs are only
+    // written by a chunk's last kernels and the accumulators are initialised by its first, so a repeat is clean.
+    // A caller-given chunk size is taken as is, with worst-case queues.
+    double margin = 1.5;
+    if (const char *e = getenv("RT_CHUNK_MARGIN")) margin = atof(e);  // (test knob: < 1 forces the overflow-and-repeat path)
+    std::vector<uint32_t> hc(RT_CNT_WORDS, 0);
+    size_t done = 0;            // tiles of this rank rendered so far
+    bool force_worst = false;   // the chunk being repeated after an overflow
+    struct Plan { size_t tiles, samples; QueueSizes z; bool optimistic; };
+    auto planChunk = [&](size_t remaining, bool worst, Plan &pl) -> int {
+        pl.optimistic = p->chunk_samples <= 0 && !worst && ctx->obs_valid && p->max_depth <= ctx->obs_depth;
+        const double ray_fan = pl.optimistic ? std::min((double)fo, std::max(1.0, margin * ctx->obs_ray)) : (double)fo;
+        const double sh_fan = pl.optimistic ? std::min((double)fo * nl, std::max(1.0, margin * ctx->obs_sh)) : (double)fo * nl;
+        size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : pl.optimistic ? (size_t)RT_SAMPLE_MASK : (size_t)1 << 26;
+        chunk_samples = std::min<size_t>(std::min<size_t>(chunk_samples, RT_SAMPLE_MASK), remaining * per_tile);
+        if (p->chunk_samples <= 0) {
+            // what fits 32-bit indices and 7/8 of the memory that is FREE on this device (torch, RCCL or other contexts
+            // may hold part of the HBM) plus what this context's workspace already holds
+            size_t free_b = 0, total_b = 0;
+            HIPOK(hipMemGetInfo(&free_b, &total_b));
+            const size_t budget = (free_b + ctx->ws_bytes) / 8 * 7;
+            while (chunk_samples > per_tile) {
+                const QueueSizes z = queueSizes(ctx, chunk_samples, ray_fan, sh_fan, nl);
+                if (z.fits32 && z.bytes <= budget) break;
+                chunk_samples = pl.optimistic ? chunk_samples / 8 * 7 : chunk_samples / 2;
+            }
+        }
+        pl.tiles = std::min(std::max<size_t>(1, chunk_samples / per_tile), remaining);
+        {  // equal chunks over what is left: no small straggler at the end of the frame
+            const size_t nc = (remaining + pl.tiles - 1) / pl.tiles;
+            pl.tiles = (remaining + nc - 1) / nc;
+        }
+        pl.samples = pl.tiles * per_tile;
+        pl.z = queueSizes(ctx, pl.samples, ray_fan, sh_fan, nl);
+        return 0;
+    };
+    while (done < (size_t)n_local) {
+        Plan pl;
+        if (planChunk((size_t)n_local - done, force_worst, pl)) return 1;
+        const bool optimistic = pl.optimistic;
+        const size_t chunk_tiles = pl.tiles, samples = pl.samples;
+        if (ensureWorkspace(ctx, samples, pl.z)) return 1;
+        const uint32_t tile0 = (uint32_t)done, ntiles = (uint32_t)chunk_tiles;
         HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
         // (the sample accumulators need no clearing: level-0 k_shade stores every slot of the chunk)
         kt.begin(0);
         rtLaunchGenPrimary(cfg, f, ctx->q, tile0, ntiles);
         kt.end();
-        runLevels(ctx, ctx->q, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)ntiles * per_tile);
+        runLevels(ctx, ctx->q, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)samples);
         kt.begin(4);
         rtLaunchResolve(cfg, f, ctx->q, tile0, ntiles, d_rgb8, d_rgbf);
         kt.end();
-        HIPOK(hipMemcpyAsync(ctx->d_chunk_counters.p + c * RT_CNT_WORDS, ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t),
-                             hipMemcpyDeviceToDevice, stream));
+        HIPOK(hipMemcpyAsync(hc.data(), ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPOK(hipStreamSynchronize(stream));
+        HIPOK(hipGetLastError());
+        st->chunks++;
+        if (hc[RT_CNT_OVERFLOW] && optimistic) {  // the scene out-grew what was seen so far: again, sized for the worst case
+            st->chunk_retries++;
+            st->launches_closest -= (uint64_t)p->max_depth + 1;
+            st->launches_any -= (uint64_t)p->max_depth + 1;
+            ctx->obs_valid = false;
+            force_worst = true;
+            continue;
+        }
+        addCounters(st, hc.data(), p->max_depth);
+        if (!hc[RT_CNT_OVERFLOW]) {
+            double r = 1.0, sh = 0.0;
+            for (int d = 0; d <= p->max_depth && d < 16; d++) {
+                r = std::max(r, (double)hc[RT_CNT_RAYS(d)] / (double)samples);
+                sh = std::max(sh, (double)hc[RT_CNT_SHADOW(d)] / (double)samples);
+            }
+            if (!ctx->obs_valid) ctx->obs_ray = ctx->obs_sh = 0.0;
+            ctx->obs_ray = std::max(ctx->obs_ray, r);
+            ctx->obs_sh = std::max(ctx->obs_sh, sh);
+            ctx->obs_depth = ctx->obs_valid ? std::max(ctx->obs_depth, p->max_depth) : p->max_depth;
+            ctx->obs_valid = true;
+        }
+        force_worst = false;
+        done += chunk_tiles;
     }
     HIPOK(hipEventRecord(ev1, stream));
     HIPOK(hipStreamSynchronize(stream));
@@ -401,13 +469,17 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     st->ms_total = ms;
+    if (n_local > 0 && p->chunk_samples <= 0) {
+        // What a repeat of this frame will want, now that its fan-out is known: growing tens of GB of queues takes
+        // seconds (hipFree + hipMalloc), so it is done here, at the end of the frame that found out, not inside the next
+        // one.  A no-op in steady state; a failure is not this frame's (the next call sizes its workspace anew).
+        Plan pl;
+        if (!planChunk((size_t)n_local, false, pl)) (void)ensureWorkspace(ctx, pl.samples, pl.z);
+    }
     double cls[6] = {0, 0, 0, 0, 0, 0};
     kt.collect(cls);
     st->ms_gen = cls[0]; st->ms_closest = cls[1]; st->ms_shade = cls[2]; st->ms_any = cls[3]; st->ms_resolve = cls[4];
     st->ms_packet = cls[5];
-    std::vector<uint32_t> hc(std::max<size_t>(n_chunks, 1) * RT_CNT_WORDS, 0);
-    if (n_chunks) HIPOK(hipMemcpy(hc.data(), ctx->d_chunk_counters.p, n_chunks * RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (size_t c = 0; c < n_chunks; c++) addCounters(st, &hc[c * RT_CNT_WORDS], p->max_depth);
     // primary samples = valid pixels of this rank's tiles x spp
     {
         uint64_t pix = 0;
@@ -483,7 +555,7 @@ int rt_destroy(rt_context *ctx) {
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
     ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_general.release();
-    ctx->d_counters.release(); ctx->d_chunk_counters.release();
+    ctx->d_counters.release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -811,6 +883,7 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     HIPOK(hipDeviceSynchronize());
     ctx->commit_stats.ms_upload = nowMs() - t0;
     ctx->committed = true;
+    ctx->obs_valid = false;  // a new scene: its fan-out is unknown
     return 0;
 }
 }  // namespace

@@ -1,0 +1,42 @@
+"""Chunk sizing from the observed fan-out (rt_abi.cpp: renderTiles): after the first chunks of a scene the queues are sized
+for 1.5 x the fan-out seen so far instead of the worst case, so a frame needs fewer, larger chunks; a chunk that overflows
+its queues after all is rendered again with worst-case queues.  Either way the images are those of fixed small chunks."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import get_scene
+
+
+@pytest.mark.gpu
+def test_adaptive_chunks_and_overflow_repeat_change_no_bit():
+    from raytracer_amd.renderer import Renderer
+    r = Renderer(0).set_scene(get_scene("competition", False))
+    w, h, spp = 1920, 1080, 16
+    want = ("rgb8", "primid", "rgbf")
+    ref = r.render(w, h, spp=spp, chunk_samples=1 << 22, collect_stats=1, want=want)   # fixed chunks, worst-case queues
+    assert ref["stats"]["chunks"] >= 8 and ref["stats"]["chunk_retries"] == 0
+    a = r.render(w, h, spp=spp, collect_stats=1, want=want)                              # sized from what `ref` saw
+    assert a["stats"]["chunks"] == 1 and a["stats"]["chunk_retries"] == 0
+    for k in want:
+        assert np.array_equal(a[k].view(np.uint32) if k == "rgbf" else a[k], ref[k].view(np.uint32) if k == "rgbf" else ref[k]), k
+    for k in ("rays_closest", "rays_shadow", "shadow_zero", "shadow_culled", "hits_shaded"):
+        assert a["stats"][k] == ref["stats"][k], k
+
+    # A fresh context (queues only ever grow inside one): a small frame gives it a fan-out, then the full view is rendered
+    # with queues sized for a twentieth of that -- the chunk overflows and is repeated with worst-case queues.
+    r2 = Renderer(0).set_scene(get_scene("competition", False))
+    r2.render(64, 48, spp=4, want=())
+    os.environ["RT_CHUNK_MARGIN"] = "0.05"
+    try:
+        b = r2.render(w, h, spp=spp, collect_stats=1, want=want)
+    finally:
+        del os.environ["RT_CHUNK_MARGIN"]
+    assert b["stats"]["chunk_retries"] >= 1 and b["stats"]["queue_overflow"] == 0
+    for k in want:
+        assert np.array_equal(b[k].view(np.uint32) if k == "rgbf" else b[k], ref[k].view(np.uint32) if k == "rgbf" else ref[k]), k
+    for k in ("rays_closest", "rays_shadow", "shadow_zero", "shadow_culled", "hits_shaded"):
+        assert b["stats"][k] == ref["stats"][k], k
+    c = r2.render(w, h, spp=spp, collect_stats=1, want=("rgb8",))                       # and the next frame is back to normal
+    assert c["stats"]["chunk_retries"] == 0 and np.array_equal(c["rgb8"], ref["rgb8"])
