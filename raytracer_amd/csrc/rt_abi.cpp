@@ -113,6 +113,7 @@ struct rt_context {
     double obs_ray = 0.0, obs_sh = 0.0;
     int obs_depth = -1;
     DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shC;
+    DevBuf<uint8_t> d_shL;
     DevBuf<float> d_rayR[2];
     DevBuf<float2> d_hits;
     DevBuf<long long> d_accum;
@@ -150,7 +151,7 @@ QueueSizes queueSizes(const rt_context *ctx, size_t samples, double ray_fan, dou
     z.ray_cap = rays + 2 * waves * RT_SLAB_MAX + rays / 64 + 128;
     z.sh_cap = shadows + 2 * waves * nl * RT_SLAB_MAX;
     z.fits32 = z.ray_cap < (1ull << 32) && z.sh_cap < (1ull << 32);
-    z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + z.sh_cap * 32 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
+    z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + z.sh_cap * 33 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
     return z;
 }
 QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl) {  // worst case
@@ -184,7 +185,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
             if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
         }
         if (ctx->d_hits.alloc(ray_cap + 1)) return 1;
-        if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap)) return 1;
+        if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap) || ctx->d_shL.alloc(sh_cap)) return 1;
         if (ctx->d_accum.alloc(samples * 3)) return 1;
         if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
         if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
@@ -196,14 +197,14 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
     if (grow() || ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) {
         const std::string why = g_err;
         for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); ctx->d_split[k].release(); }
-        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_resid.release(); ctx->d_general.release();
+        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_accum.release(); ctx->d_resid.release(); ctx->d_general.release();
         ctx->ws_samples = 0;
         ctx->ws_bytes = 0;
         ctx->q = RtQueues{};
         ctx->q.spill = ctx->d_spill.p;
         return fail("workspace allocation failed (workspace released): " + why);
     }
-    ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + sh_cap * 32 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
+    ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + sh_cap * 33 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
     ctx->ws_samples = samples;
     RtQueues &q = ctx->q;
     for (int k = 0; k < 2; k++) {
@@ -214,6 +215,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
     q.hits = ctx->d_hits.p;
     q.shA = ctx->d_shA.p;
     q.shC = ctx->d_shC.p;
+    q.shL = ctx->d_shL.p;
     q.accum = ctx->d_accum.p;
     q.counters = ctx->d_counters.p;
     q.spill = ctx->d_spill.p;
@@ -554,7 +556,7 @@ int rt_destroy(rt_context *ctx) {
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
-    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_accum.release(); ctx->d_general.release();
+    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_accum.release(); ctx->d_general.release();
     ctx->d_counters.release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -962,6 +964,7 @@ bool carveStatic(unsigned char *base, size_t bytes, size_t samples, int fanout, 
     q.hits = (float2 *)take((ray_cap + 1) * sizeof(float2));
     q.shA = (float4 *)take(sh_cap * sizeof(float4));
     q.shC = (float4 *)take(sh_cap * sizeof(float4));
+    q.shL = (uint8_t *)take(sh_cap);
     q.accum = (long long *)take(samples * 3 * sizeof(long long));
     q.resid = (uint32_t *)take(std::max(sh_cap, ray_cap) * sizeof(uint32_t));
     q.general = (uint32_t *)take(ray_cap * sizeof(uint32_t));

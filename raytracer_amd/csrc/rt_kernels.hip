@@ -443,10 +443,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 // Shadow-queue record -> the Ray of is_shadowed() (main.cpp:49): the record holds the shaded point and the light's
 // index; direction, light distance and the epsilon-offset origin are recomputed with the expressions k_shade uses
 // (same operations, same order => same bits), which keeps the record at 32 bytes instead of 48.
-RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, RtRay &r, float &dist, uint32_t &sample) {
-    const uint32_t wd = __float_as_uint(A.w);
-    sample = wd & RT_SAMPLE_MASK;
-    const V3 P = v3(A.x, A.y, A.z), lp = ld3(sc.lights[wd >> 28].pos);
+RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, uint32_t light, RtRay &r, float &dist, uint32_t &sample) {
+    sample = __float_as_uint(A.w) & RT_SAMPLE_MASK;
+    const V3 P = v3(A.x, A.y, A.z), lp = ld3(sc.lights[light].pos);
     const V3 ld = normalize(lp - P);  // main.cpp:97
     dist = length(lp - P);            // :98
     r.o = P + RT_EPSILON * ld;        // :49
@@ -627,7 +626,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             const bool take = !has && rank < avail;
             const uint32_t old_i = ray_i, old_sample = sample;
             float4 A = make_float4(0, 0, 0, 0), B = A, C = A;
-            uint32_t item_ref = RT_NODE_DONE;
+            uint32_t item_ref = RT_NODE_DONE, light = 0;
             bool nothing = false;  // the slot holds no ray
             if (take) {
                 if (SPLIT) {
@@ -651,6 +650,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     ray_i = INDIRECT ? q.resid[pos] : pos;
                 }
                 if (!nothing) A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
+                if (ANY && !nothing) light = q.shL[ray_i];
                 if (!ANY) B = q.rayB[buf][ray_i];
                 if (ANY && !SPLIT) nothing = __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
             }
@@ -659,7 +659,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             if (take && !nothing) {
                 float ldist = 0.0f;
                 if (ANY) {
-                    rtShadowRay(sc, A, w.r, ldist, sample);
+                    rtShadowRay(sc, A, light, w.r, ldist, sample);
                 } else {
                     w.r.o = v3(A.x, A.y, A.z);
                     w.r.d = v3(B.x, B.y, B.z);
@@ -824,11 +824,10 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
         if (!ANY) B = q.rayB[buf][i];
     }
     const bool hole = ANY && __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
-    if (hole) A.w = 0.0f;  // (a hole's word would decode to light 15: past the scene's light array)
     uint32_t sample = __float_as_uint(B.w);
     float ldist = 0.0f;
     if (ANY) {
-        rtShadowRay(sc, A, w.r, ldist, sample);
+        rtShadowRay(sc, A, (valid && !hole) ? (uint32_t)q.shL[i] : 0u, w.r, ldist, sample);  // (a hole's light byte was never written)
     } else {
         w.r.o = v3(A.x, A.y, A.z);
         w.r.d = v3(B.x, B.y, B.z);
@@ -1327,8 +1326,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 endv = end;
             }
             if (lit) {
-                if (slot < q.shadow_cap) {  // 32-byte record: point + (sample, light), pending colour (rtShadowRay rebuilds the ray)
-                    q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | ((uint32_t)l << 28)));
+                if (slot < q.shadow_cap) {  // 33-byte record: point + sample, light, pending colour (rtShadowRay rebuilds the ray)
+                    q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample));
+                    q.shL[slot] = (uint8_t)l;
                     q.shC[slot] = make_float4(c3.x, c3.y, c3.z, 0.0f);
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);

@@ -7,7 +7,7 @@
 
 #define RT_TILE 16              // image tile edge, reference main.cpp:565
 #define RT_TILE_PIXELS 256
-#define RT_MAX_LIGHTS 16         // the light index shares a word with the 28-bit sample index in the shadow queue
+#define RT_MAX_LIGHTS 16         // k_shade keeps a slab cursor per light in lanes 0..15 of a register (+ lane 16 for the ray slab)
 #define RT_MAX_SPHERES 64
 #define RT_MAX_PLANES 64
 #ifndef RT_LDS_STACK
@@ -152,9 +152,9 @@ struct RtFrameDev {
 #define RT_ID_TRI_MASK 0x0FFFFFFFu            // triangle slot of a triangle id
 #define RT_GENERAL_HOLE 0xFFFFFFFFu  // unused slot of a wave's slab of the general list (RtQueues::general)
 
-// ray flags packed above the sample index (28 bits of sample index)
-#define RT_SAMPLE_MASK 0x0FFFFFFFu
-#define RT_FLAG_HAS_REFR_SIBLING 0x10000000u  // reflection ray whose refraction sibling sits in the next slot
+// ray flags packed above the sample index (30 bits of sample index: a chunk holds up to 2^30 - 1 primary samples)
+#define RT_SAMPLE_MASK 0x3FFFFFFFu
+#define RT_FLAG_HAS_REFR_SIBLING 0x40000000u  // reflection ray whose refraction sibling sits in the next slot
 #define RT_SHADOW_HOLE 0xFFFFFFFFu            // w of a shadow record that holds no ray (unused slot of a k_shade slab)
 #ifndef RT_SLAB_MAX
 #define RT_SLAB_MAX 1024u                    // slots a k_shade wave reserves at a time, per light / for the next level
@@ -166,10 +166,10 @@ struct RtFrameDev {
 #define RT_SHADE_SEGMENT 1024u                // consecutive queue entries a k_shade wave shades before it jumps
 #endif
 #define RT_BLOCK 256                         // threads per block of every kernel
-#define RT_FLAG_INVALID 0x20000000u           // slot of a pixel outside the image or unused slab slot: traced as a miss, never shaded
+#define RT_FLAG_INVALID 0x80000000u           // slot of a pixel outside the image or unused slab slot: traced as a miss, never shaded
 
 // Wavefront queues of one chunk (device pointers).  Rays: A = (origin.xyz, weight), B = (direction.xyz, sample|flags),
-// R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (shaded point, sample | light << 28),
+// R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (shaded point, sample), L = light index,
 // C = (pending rgb, 0); origin, direction and light distance are recomputed from the point (rtShadowRay).
 struct RtQueues {
     float4 *rayA[2];
@@ -177,6 +177,7 @@ struct RtQueues {
     float *rayR[2];
     float2 *hits;
     float4 *shA, *shC;
+    uint8_t *shL;              // light index of a shadow record (one byte per slot)
     long long *accum;          // [chunk samples][3] fixed point
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
