@@ -201,7 +201,8 @@ def main():
             if t.get("kernel_source_hash") != khash:
                 traffic_src = "profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): not used"
             elif t.get("workload") == result["config"]["workload"] and name in t.get("kernels", {}):
-                traffic = t["kernels"][name]["hbm_bytes_per_launch"]
+                # per launch of THIS run (the profiled frame may have been cut into more chunks, i.e. more launches)
+                traffic = t["kernels"][name]["hbm_bytes_per_frame"] / launches
                 traffic_src = "profiles/r02_pmc_traffic.json (same kernel sources, hash %s)" % khash
         result["roofline"] = {
             "kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -374,8 +374,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     hipEvent_t ev0, ev1;
     HIPOK(hipEventCreate(&ev0));
     HIPOK(hipEventCreate(&ev1));
-    HIPOK(hipEventRecord(ev0, stream));
-    if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
+    bool started = false;  // ev0 is recorded once the first chunk's workspace exists: ms_total is GPU time, not hipMalloc time
     // Chunks of whole tiles.  Large chunks are faster (deep levels hold few rays, and every launch ends with its longest
     // ray: 8 chunks of 64 Mi samples cost 7 % more than 2 of 265 M on the 4K / 64 spp frame), but a chunk's queues must
     // hold its fullest level, and the WORST case (every hit spawns a pair, every light faces every hit: 2^depth rays and
@@ -425,6 +424,11 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         const bool optimistic = pl.optimistic;
         const size_t chunk_tiles = pl.tiles, samples = pl.samples;
         if (ensureWorkspace(ctx, samples, pl.z)) return 1;
+        if (!started) {
+            HIPOK(hipEventRecord(ev0, stream));
+            if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
+            started = true;
+        }
         const uint32_t tile0 = (uint32_t)done, ntiles = (uint32_t)chunk_tiles;
         HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
         // (the sample accumulators need no clearing: level-0 k_shade stores every slot of the chunk)
@@ -463,6 +467,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         force_worst = false;
         done += chunk_tiles;
     }
+    if (!started) HIPOK(hipEventRecord(ev0, stream));
     HIPOK(hipEventRecord(ev1, stream));
     HIPOK(hipStreamSynchronize(stream));
     HIPOK(hipGetLastError());
