@@ -91,8 +91,13 @@ typedef struct rt_render_params {
     int32_t collect_stats;  /* bit0: count BVH node fetches / triangle tests and the longest walk in-kernel;
                                bit1: time every kernel class with HIP events on the launch stream (ms_gen ...);
                                bit2: wave-time profile of the kernels (prof_closest / prof_any / prof_shade; much slower) */
-    int32_t _pad;
+    int32_t flags;          /* rt_render_flags; 0 = a frame that others like it will follow */
 } rt_render_params;
+
+/* rt_render_params.flags */
+#define RT_RENDER_SINGLE_FRAME 1 /* one image and no more (the reference's main()): the library then neither grows its
+                                    queues inside the frame nor prepares them for a repeat of it -- allocating tens of
+                                    GB costs seconds, which only pays when further frames follow */
 
 typedef struct rt_stats {
     uint64_t primary_samples;

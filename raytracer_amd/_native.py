@@ -45,7 +45,7 @@ class RenderParams(C.Structure):
     _fields_ = [
         ("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
         ("seed", C.c_uint32), ("jitter_mode", C.c_int32), ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
-        ("chunk_samples", C.c_int64), ("collect_stats", C.c_int32), ("_pad", C.c_int32),
+        ("chunk_samples", C.c_int64), ("collect_stats", C.c_int32), ("flags", C.c_int32),
     ]
 
 

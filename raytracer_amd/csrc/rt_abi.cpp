@@ -161,6 +161,7 @@ QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl)
 // rays of the deepest level per primary sample, worst case: every hit spawns a reflection/refraction pair (main.cpp:148-205)
 int worstFanout(int max_depth) { return 1 << std::min(std::max(max_depth, 0), 15); }
 
+double nowMs();
 int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z);
 int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights) {
     return ensureWorkspace(ctx, samples, queueSizes(ctx, samples, worstFanout(max_depth), std::max(n_lights, 1)));
@@ -192,6 +193,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
         if (ctx->d_general.alloc(ray_cap)) return 1;
         return 0;
     };
+    const double t_grow0 = nowMs();
     size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
     if (const char *e = getenv("RT_SPLIT_CAP")) split_cap = (size_t)std::max(64, atoi(e));  // (test knob: forces the no-room path)
     if (grow() || ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) {
@@ -206,6 +208,9 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
     }
     ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + sh_cap * 33 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
     ctx->ws_samples = samples;
+    if (getenv("RT_VERBOSE"))
+        std::fprintf(stderr, "[rt] workspace grown to %zu samples, %zu ray slots, %zu shadow slots (%.1f GB) in %.0f ms\n", samples, ray_cap,
+                     sh_cap, (double)ctx->ws_bytes / 1e9, nowMs() - t_grow0);
     RtQueues &q = ctx->q;
     for (int k = 0; k < 2; k++) {
         q.rayA[k] = ctx->d_rayA[k].p;
@@ -385,28 +390,43 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     // count what does not fit; nothing is written out of bounds) is rendered again at worst-case size: outputs are only
     // written by a chunk's last kernels and the accumulators are initialised by its first, so a repeat is clean.
     // A caller-given chunk size is taken as is, with worst-case queues.
-    double margin = 1.5;
+    double margin = 1.5, ws_frac = 0.5;
     if (const char *e = getenv("RT_CHUNK_MARGIN")) margin = atof(e);  // (test knob: < 1 forces the overflow-and-repeat path)
+    if (const char *e = getenv("RT_WORKSPACE_FRACTION")) ws_frac = std::min(0.875, std::max(0.05, atof(e)));
     std::vector<uint32_t> hc(RT_CNT_WORDS, 0);
     size_t done = 0;            // tiles of this rank rendered so far
     bool force_worst = false;   // the chunk being repeated after an overflow
     struct Plan { size_t tiles, samples; QueueSizes z; bool optimistic; };
     auto planChunk = [&](size_t remaining, bool worst, Plan &pl) -> int {
+        const bool single = (p->flags & RT_RENDER_SINGLE_FRAME) != 0;
         pl.optimistic = p->chunk_samples <= 0 && !worst && ctx->obs_valid && p->max_depth <= ctx->obs_depth;
         const double ray_fan = pl.optimistic ? std::min((double)fo, std::max(1.0, margin * ctx->obs_ray)) : (double)fo;
         const double sh_fan = pl.optimistic ? std::min((double)fo * nl, std::max(1.0, margin * ctx->obs_sh)) : (double)fo * nl;
-        size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples : pl.optimistic ? (size_t)RT_SAMPLE_MASK : (size_t)1 << 26;
+        // (a single frame keeps its worst-case first chunk small: that chunk's queues are all it will ever allocate)
+        size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples
+                               : pl.optimistic ? (size_t)RT_SAMPLE_MASK : (size_t)1 << (single ? 24 : 26);
         chunk_samples = std::min<size_t>(std::min<size_t>(chunk_samples, RT_SAMPLE_MASK), remaining * per_tile);
         if (p->chunk_samples <= 0) {
             // what fits 32-bit indices and 7/8 of the memory that is FREE on this device (torch, RCCL or other contexts
             // may hold part of the HBM) plus what this context's workspace already holds
             size_t free_b = 0, total_b = 0;
             HIPOK(hipMemGetInfo(&free_b, &total_b));
-            const size_t budget = (free_b + ctx->ws_bytes) / 8 * 7;
+            // Worst-case queues may take 7/8 of it (deep bounce budgets need the room to fit at all); queues sized from
+            // the observed fan-out stop at `ws_frac` (half by default, RT_WORKSPACE_FRACTION): larger chunks than that buy
+            // ~1 % (profiles/r02_chunks.md) and the memory has other users (scene, outputs, torch, RCCL).
+            const size_t avail = free_b + ctx->ws_bytes;
+            const size_t budget = pl.optimistic ? (size_t)((double)avail * ws_frac) : avail / 8 * 7;
             while (chunk_samples > per_tile) {
                 const QueueSizes z = queueSizes(ctx, chunk_samples, ray_fan, sh_fan, nl);
-                if (z.fits32 && z.bytes <= budget) break;
+                if (z.fits32 && z.bytes + z.bytes / 8 <= budget) break;  // (+ 1/8: the headroom a growing queue gets)
                 chunk_samples = pl.optimistic ? chunk_samples / 8 * 7 : chunk_samples / 2;
+            }
+            if (single && pl.optimistic && ctx->q.ray_cap) {  // no growth inside a single frame: what the queues hold as they are
+                while (chunk_samples > per_tile) {
+                    const QueueSizes z = queueSizes(ctx, chunk_samples, ray_fan, sh_fan, nl);
+                    if (z.ray_cap <= ctx->q.ray_cap && z.sh_cap <= ctx->q.shadow_cap) break;
+                    chunk_samples = chunk_samples / 8 * 7;
+                }
             }
         }
         pl.tiles = std::min(std::max<size_t>(1, chunk_samples / per_tile), remaining);
@@ -423,7 +443,18 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         if (planChunk((size_t)n_local - done, force_worst, pl)) return 1;
         const bool optimistic = pl.optimistic;
         const size_t chunk_tiles = pl.tiles, samples = pl.samples;
-        if (ensureWorkspace(ctx, samples, pl.z)) return 1;
+        QueueSizes need = pl.z;
+        size_t need_samples = samples;
+        if (optimistic && !(p->flags & RT_RENDER_SINGLE_FRAME) && (size_t)n_local > chunk_tiles) {
+            // queues that must grow now grow to what a repeat of the WHOLE frame will want: one reallocation, not two
+            Plan whole;
+            if (planChunk((size_t)n_local, false, whole)) return 1;
+            need.ray_cap = std::max(need.ray_cap, whole.z.ray_cap);
+            need.sh_cap = std::max(need.sh_cap, whole.z.sh_cap);
+            need.fits32 = need.fits32 && whole.z.fits32;
+            need_samples = std::max(need_samples, whole.samples);
+        }
+        if (ensureWorkspace(ctx, need_samples, need)) return 1;
         if (!started) {
             HIPOK(hipEventRecord(ev0, stream));
             if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
@@ -476,7 +507,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     st->ms_total = ms;
-    if (n_local > 0 && p->chunk_samples <= 0) {
+    if (n_local > 0 && p->chunk_samples <= 0 && !(p->flags & RT_RENDER_SINGLE_FRAME)) {
         // What a repeat of this frame will want, now that its fan-out is known: growing tens of GB of queues takes
         // seconds (hipFree + hipMalloc), so it is done here, at the end of the frame that found out, not inside the next
         // one.  A no-op in steady state; a failure is not this frame's (the next call sizes its workspace anew).

@@ -310,6 +310,7 @@ rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
     p.jitter_mode = opt.jitterMode;
     p.tile_rank = 0;
     p.tile_world = 1;
+    p.flags = opt.singleFrame ? RT_RENDER_SINGLE_FRAME : 0;
     rt_camera cam = camera.toC();
     std::vector<uint8_t> rgb8((size_t)3 * p.width * p.height);
     rt_stats st{};

@@ -83,6 +83,8 @@ struct RenderOptions {
     // HIP devices to render on.  Empty or one entry: one GPU (RT_DEVICE or 0).  More: the frame's tiles are interleaved
     // over these GPUs and gathered with RCCL (rt_multi_render) -- what `#pragma omp parallel for` was at main.cpp:607.
     std::vector<int> devices;
+    // one image and no more (the reference's main()): the library does not size its queues for a repeat of the frame
+    bool singleFrame = false;
 };
 
 // Stands where main.cpp:607-650 stood: renders the global scene into `image` on the GPU.

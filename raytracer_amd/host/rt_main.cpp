@@ -57,6 +57,7 @@ int main(int argc, const char *argv[]) {
         opt.spp = spp;
         opt.maxDepth = depth;
         opt.textureDir = assets + "/textures";
+        opt.singleFrame = true;  // this program renders one image, like the reference's main()
         for (int g = 0; g < gpus && gpus > 1; g++) opt.devices.push_back(g);
         const auto t1 = std::chrono::steady_clock::now();
         const rt_stats st = render(image, cam, opt);

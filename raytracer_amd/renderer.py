@@ -84,9 +84,11 @@ class Renderer:
                               chunk_samples=chunk_samples, collect_stats=collect_stats)
 
     def render(self, width, height, spp=4, max_depth=3, seed=0, jitter_mode=N.JITTER_AUTO, camera=None,
-               chunk_samples=0, collect_stats=0, want=("rgb8", "rgbf", "primid")):
-        """Whole image on this GPU.  Returns dict(rgb8 u8[h,w,3], rgbf f32[h,w,3], primid u32[h,w], stats)."""
+               chunk_samples=0, collect_stats=0, want=("rgb8", "rgbf", "primid"), single_frame=False):
+        """Whole image on this GPU.  Returns dict(rgb8 u8[h,w,3], rgbf f32[h,w,3], primid u32[h,w], stats).
+        single_frame: RT_RENDER_SINGLE_FRAME (no queue growth inside the frame or for a repeat of it)."""
         p = self._params(width, height, spp, max_depth, seed, jitter_mode, 0, 1, chunk_samples, collect_stats)
+        p.flags = 1 if single_frame else 0
         cam = camera if camera is not None else self.scene.camera
         out = {}
         rgb8 = np.zeros((height, width, 3), np.uint8) if "rgb8" in want else None

@@ -40,3 +40,18 @@ def test_adaptive_chunks_and_overflow_repeat_change_no_bit():
         assert b["stats"][k] == ref["stats"][k], k
     c = r2.render(w, h, spp=spp, collect_stats=1, want=("rgb8",))                       # and the next frame is back to normal
     assert c["stats"]["chunk_retries"] == 0 and np.array_equal(c["rgb8"], ref["rgb8"])
+
+
+@pytest.mark.gpu
+def test_single_frame_flag_changes_no_bit():
+    """RT_RENDER_SINGLE_FRAME (what raytracer_hip sets): small worst-case first chunk, later chunks sized to the queues that
+    exist, no growth for a repeat -- same image, and the workspace does not grow between two such frames."""
+    from raytracer_amd.renderer import Renderer
+    w, h, spp = 1920, 1080, 16
+    ref = Renderer(0).set_scene(get_scene("competition", False)).render(w, h, spp=spp, chunk_samples=1 << 22, want=("rgb8", "primid"))
+    r = Renderer(0).set_scene(get_scene("competition", False))
+    a = r.render(w, h, spp=spp, want=("rgb8", "primid"), single_frame=True)
+    b = r.render(w, h, spp=spp, want=("rgb8", "primid"), single_frame=True)
+    assert a["stats"]["chunks"] >= 2 and a["stats"]["chunk_retries"] == 0
+    for x in (a, b):
+        assert np.array_equal(x["rgb8"], ref["rgb8"]) and np.array_equal(x["primid"], ref["primid"])
