@@ -316,9 +316,10 @@ void runLevels(rt_context *ctx, const RtQueues &q, const RtLaunchCfg &cfg, int m
         kt.begin(3);
         rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats);
         kt.end();
-        if (st) {
-            st->launches_closest++;
-            st->launches_any++;
+        if (st) {  // launches that walk a level's queue (what a kernel trace lists as k_closest<.., 0> / k_any<.., 0>): the
+                   // hand-over launch behind a packet level and the split rounds are not counted
+            if (!(level == 0 && level0_traced) && !rtLevelUsesPackets(cfg, level, false)) st->launches_closest++;
+            if (!rtLevelUsesPackets(cfg, level, true)) st->launches_any++;
         }
     }
 }
@@ -461,6 +462,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
             started = true;
         }
         const uint32_t tile0 = (uint32_t)done, ntiles = (uint32_t)chunk_tiles;
+        const rt_stats before = *st;
         HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
         // (the sample accumulators need no clearing: level-0 k_shade stores every slot of the chunk)
         kt.begin(0);
@@ -473,15 +475,15 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         HIPOK(hipMemcpyAsync(hc.data(), ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPOK(hipStreamSynchronize(stream));
         HIPOK(hipGetLastError());
-        st->chunks++;
         if (hc[RT_CNT_OVERFLOW] && optimistic) {  // the scene out-grew what was seen so far: again, sized for the worst case
+            *st = before;  // (launch counts of the discarded attempt)
+            st->chunks++;
             st->chunk_retries++;
-            st->launches_closest -= (uint64_t)p->max_depth + 1;
-            st->launches_any -= (uint64_t)p->max_depth + 1;
             ctx->obs_valid = false;
             force_worst = true;
             continue;
         }
+        st->chunks++;
         addCounters(st, hc.data(), p->max_depth);
         if (!hc[RT_CNT_OVERFLOW]) {
             double r = 1.0, sh = 0.0;
