@@ -172,21 +172,23 @@ RT_DEV bool rtTriStep(const RtSceneDev &sc, RtWalk &w, RtTraversalStats &st) {
     T.B = v3(q1.x, q1.y, q1.z);
     T.C = v3(q2.x, q2.y, q2.z);
     T.n = v3(q0.w, q1.w, q2.w);
-    float t;
-    if (rtTriHit(T, w.r, w.best_t, t)) {
-        if (ANY) return true;
+    float t = 0.0f;
+    const bool hit = rtTriHit(T, w.r, w.best_t, t);
+    if (ANY) {
+        if (hit) return true;
+    } else {
         const int obj = (int)__float_as_uint(q3.x);
         const uint32_t rank = __float_as_uint(q3.y);
         // strict minimum; on an exact tie the earlier object wins (main.cpp:67) and inside a mesh the earlier
         // candidate of the reference's order (MeshLoader.h:399-404).  A miss (distance INFINITY) never loses to inf.
-        const bool take = t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
-                                           (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
-        if (take) {
-            w.best_t = t;
-            w.best_id = ((w.pend & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes) | __float_as_uint(q3.w);  // (| RT_ID_GENERAL flag)
-            w.best_obj = obj;
-            w.best_rank = rank;
-        }
+        // (ONE set of selects after the test: updating the best hit inside the test's nested early exits made the
+        // compiler copy the four unchanged values on every exit edge, 20 v_mov per triangle step)
+        const bool take = hit && (t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
+                                                   (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank))));
+        w.best_t = take ? t : w.best_t;
+        w.best_id = take ? (((w.pend & RT_NODE_INDEX_MASK) - (uint32_t)sc.n_nodes) | __float_as_uint(q3.w)) : w.best_id;  // (| RT_ID_GENERAL flag)
+        w.best_obj = take ? obj : w.best_obj;
+        w.best_rank = take ? rank : w.best_rank;
     }
     if ((w.pend >> 28) & 7u) w.pend += 1u - 0x10000000u;  // next triangle of the leaf
     else w.pend = RT_NODE_DONE;
@@ -935,23 +937,22 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
                     T.B = v3(__uint_as_float(tr[4]), __uint_as_float(tr[5]), __uint_as_float(tr[6]));
                     T.C = v3(__uint_as_float(tr[8]), __uint_as_float(tr[9]), __uint_as_float(tr[10]));
                     T.n = v3(__uint_as_float(tr[3]), __uint_as_float(tr[7]), __uint_as_float(tr[11]));
-                    float t;
-                    if (act && rtTriHit(T, w.r, w.best_t, t)) {
-                        if (ANY) {
+                    float t = 0.0f;
+                    const bool hit = act && rtTriHit(T, w.r, w.best_t, t);
+                    if (ANY) {
+                        if (hit) {
                             alive = false;  // occluded: the pending radiance is dropped
                             act = false;
-                        } else {
-                            const int obj = (int)tr[12];
-                            const uint32_t rank = tr[13];
-                            const bool take = t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
-                                                               (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank)));
-                            if (take) {
-                                w.best_t = t;
-                                w.best_id = (first + k - (uint32_t)sc.n_nodes) | tr[15];  // (| RT_ID_GENERAL flag)
-                                w.best_obj = obj;
-                                w.best_rank = rank;
-                            }
                         }
+                    } else {  // (selects after the test, as in rtTriStep)
+                        const int obj = (int)tr[12];
+                        const uint32_t rank = tr[13];
+                        const bool take = hit && (t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
+                                                                   (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank))));
+                        w.best_t = take ? t : w.best_t;
+                        w.best_id = take ? ((first + k - (uint32_t)sc.n_nodes) | tr[15]) : w.best_id;  // (| RT_ID_GENERAL flag)
+                        w.best_obj = take ? obj : w.best_obj;
+                        w.best_rank = take ? rank : w.best_rank;
                     }
                 }
                 if (ANY && !__ballot(act)) break;  // every ray of the group is occluded
