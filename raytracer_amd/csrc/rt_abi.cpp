@@ -111,9 +111,11 @@ struct rt_context {
     // Chunks are sized from it once it exists (renderTiles); reset by rt_commit.
     bool obs_valid = false;
     double obs_ray = 0.0, obs_sh = 0.0;
+    double obs_l0_share = 0.0;  // share of the last chunk's shadow rays that were level-0 rays
     int obs_depth = -1;
     DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shC;
-    DevBuf<uint8_t> d_shL;
+    DevBuf<uint8_t> d_shL, d_occ0;  // d_occ0 / d_col0: level-0 shadow results stored per [light][sample] (RtQueues::occ0)
+    DevBuf<float4> d_col0;
     DevBuf<float> d_rayR[2];
     DevBuf<float2> d_hits;
     DevBuf<long long> d_accum;
@@ -199,7 +201,7 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
     if (grow() || ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) {
         const std::string why = g_err;
         for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); ctx->d_split[k].release(); }
-        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_accum.release(); ctx->d_resid.release(); ctx->d_general.release();
+        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_occ0.release(); ctx->d_col0.release(); ctx->d_accum.release(); ctx->d_resid.release(); ctx->d_general.release();
         ctx->ws_samples = 0;
         ctx->ws_bytes = 0;
         ctx->q = RtQueues{};
@@ -221,6 +223,9 @@ int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
     q.shA = ctx->d_shA.p;
     q.shC = ctx->d_shC.p;
     q.shL = ctx->d_shL.p;
+    q.occ0 = nullptr;  // (set per chunk by renderTiles)
+    q.col0 = nullptr;
+    q.l0_stride = 0;
     q.accum = ctx->d_accum.p;
     q.counters = ctx->d_counters.p;
     q.spill = ctx->d_spill.p;
@@ -315,6 +320,7 @@ void runLevels(rt_context *ctx, const RtQueues &q, const RtLaunchCfg &cfg, int m
         kt.end();
         kt.begin(3);
         rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats);
+        if (level == 0 && q.occ0) rtLaunchFold0(cfg, q, (uint32_t)level0_rays, (int)ctx->lights.size());
         kt.end();
         if (st) {  // launches that walk a level's queue (what a kernel trace lists as k_closest<.., 0> / k_any<.., 0>): the
                    // hand-over launch behind a packet level and the split rounds are not counted
@@ -391,6 +397,8 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     // count what does not fit; nothing is written out of bounds) is rendered again at worst-case size: outputs are only
     // written by a chunk's last kernels and the accumulators are initialised by its first, so a repeat is clean.
     // A caller-given chunk size is taken as is, with worst-case queues.
+    int l0_mode = -1;  // level-0 shadow results stored instead of added: -1 = where it pays (below), 0 = never, 1 = always
+    if (const char *e = getenv("RT_L0_STORE")) l0_mode = atoi(e) != 0 ? 1 : 0;
     double margin = 1.5, ws_frac = 0.5;
     if (const char *e = getenv("RT_CHUNK_MARGIN")) margin = atof(e);  // (test knob: < 1 forces the overflow-and-repeat path)
     if (const char *e = getenv("RT_WORKSPACE_FRACTION")) ws_frac = std::min(0.875, std::max(0.05, atof(e)));
@@ -463,14 +471,28 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         }
         const uint32_t tile0 = (uint32_t)done, ntiles = (uint32_t)chunk_tiles;
         const rt_stats before = *st;
+        // Level-0 shadow results stored instead of added (RtQueues::occ0) where most of the scene's shadow rays are
+        // level-0 rays: their three 64-bit atomics each are then what bounds k_any (bunny scene: 88 -> 27 ms), while a
+        // frame whose shadow rays mostly come from deeper levels hides its atomics behind the walks and would only pay for
+        // the extra pass.  Either way the sums are the same integers.  RT_L0_STORE=0 / 1 forces the choice.
+        RtQueues cq = ctx->q;
+        const size_t nlights = ctx->lights.size();
+        const bool l0 = nlights > 0 && (l0_mode == 1 || (l0_mode < 0 && ctx->obs_valid && ctx->obs_l0_share >= 0.6));
+        if (l0) {
+            if (ctx->d_occ0.alloc(samples * nlights) || ctx->d_col0.alloc(samples * nlights)) return 1;
+            cq.occ0 = ctx->d_occ0.p;
+            cq.col0 = ctx->d_col0.p;
+            cq.l0_stride = (uint32_t)samples;
+            HIPOK(hipMemsetAsync(cq.occ0, 0, samples * nlights, stream));
+        }
         HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
         // (the sample accumulators need no clearing: level-0 k_shade stores every slot of the chunk)
         kt.begin(0);
-        rtLaunchGenPrimary(cfg, f, ctx->q, tile0, ntiles);
+        rtLaunchGenPrimary(cfg, f, cq, tile0, ntiles);
         kt.end();
-        runLevels(ctx, ctx->q, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)samples);
+        runLevels(ctx, cq, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)samples);
         kt.begin(4);
-        rtLaunchResolve(cfg, f, ctx->q, tile0, ntiles, d_rgb8, d_rgbf);
+        rtLaunchResolve(cfg, f, cq, tile0, ntiles, d_rgb8, d_rgbf);
         kt.end();
         HIPOK(hipMemcpyAsync(hc.data(), ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPOK(hipStreamSynchronize(stream));
@@ -490,6 +512,11 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
             for (int d = 0; d <= p->max_depth && d < 16; d++) {
                 r = std::max(r, (double)hc[RT_CNT_RAYS(d)] / (double)samples);
                 sh = std::max(sh, (double)hc[RT_CNT_SHADOW(d)] / (double)samples);
+            }
+            {
+                double s0 = (double)hc[RT_CNT_SHADOW(0)] - 0.0, sall = 0.0;
+                for (int d = 0; d <= p->max_depth && d < 16; d++) sall += (double)hc[RT_CNT_SHADOW(d)];
+                ctx->obs_l0_share = sall > 0 ? s0 / sall : 0.0;
             }
             if (!ctx->obs_valid) ctx->obs_ray = ctx->obs_sh = 0.0;
             ctx->obs_ray = std::max(ctx->obs_ray, r);
@@ -594,7 +621,7 @@ int rt_destroy(rt_context *ctx) {
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
-    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_accum.release(); ctx->d_general.release();
+    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_occ0.release(); ctx->d_col0.release(); ctx->d_accum.release(); ctx->d_general.release();
     ctx->d_counters.release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1003,6 +1030,9 @@ bool carveStatic(unsigned char *base, size_t bytes, size_t samples, int fanout, 
     q.shA = (float4 *)take(sh_cap * sizeof(float4));
     q.shC = (float4 *)take(sh_cap * sizeof(float4));
     q.shL = (uint8_t *)take(sh_cap);
+    q.occ0 = nullptr;
+    q.col0 = nullptr;
+    q.l0_stride = 0;
     q.accum = (long long *)take(samples * 3 * sizeof(long long));
     q.resid = (uint32_t *)take(std::max(sh_cap, ray_cap) * sizeof(uint32_t));
     q.general = (uint32_t *)take(ray_cap * sizeof(uint32_t));

@@ -33,6 +33,7 @@ void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues 
 // waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)
 inline int rtShadeBlocks(const RtLaunchCfg &cfg) { return cfg.shade_blocks > 0 ? cfg.shade_blocks : cfg.num_cus * RT_SHADE_BLOCKS_PER_CU; }
 inline int rtShadeWaves(const RtLaunchCfg &cfg) { return rtShadeBlocks(cfg) * (RT_BLOCK / 64); }
+void rtLaunchFold0(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t samples, int nlights);
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles);
 void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,

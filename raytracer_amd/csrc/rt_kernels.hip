@@ -472,7 +472,9 @@ RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, uint32_t light, RtRay &r
 #define RT_MODE_RESID 1   // the rays the packet kernel handed over (q.resid holds their queue indices)
 #define RT_MODE_SPLIT 2   // work items of split any-hit walks (round `round` of the level)
 
-template <bool ANY, int STATS, int MODE>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
+// L0: level-0 shadow results are stored, not added (RtQueues::occ0) -- an instance of its own, so that the usual one keeps
+// its registers
+template <bool ANY, int STATS, int MODE, bool L0 = false>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries, int round,
                        uint32_t budget) {
     if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(level, round)] == 0) return;  // the usual case: nothing was split
@@ -540,7 +542,8 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     bool dbg_direct = false;           // ... and it hit, but the walk goes on to see whether it agrees
 #endif
     bool occ_new = false;              // found since the wave's last refill
-    auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C) {
+    constexpr bool l0store = ANY && L0;
+    auto writeResult = [&](uint32_t ri, uint32_t smp, float4 C, uint32_t lightw) {
         bool add = true;
         if (SPLIT) {  // the item that brings the ray's outstanding count to zero speaks for the ray
             uint32_t *join = reinterpret_cast<uint32_t *>(q.shC + ri) + 3;
@@ -550,7 +553,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             occl = false;
         }
         if (COUNT && ANY && add) unocc++;
-        if (ANY && add) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
+        if (ANY && add && l0store) {
+            const size_t at = (size_t)lightw * q.l0_stride + smp;
+            q.col0[at] = C;
+            q.occ0[at] = 1;
+        } else if (ANY && add) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
             atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
@@ -660,8 +667,10 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 if (!ANY) B = q.rayB[buf][ray_i];
                 if (ANY && !SPLIT) nothing = __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
             }
+            uint32_t old_light = 0;
             if (ANY && fin) C = q.shC[old_i];
-            if (fin) writeResult(old_i, old_sample, C);
+            if (ANY && fin && l0store) old_light = q.shL[old_i];
+            if (fin) writeResult(old_i, old_sample, C, old_light);
             if (take && !nothing) {
                 float ldist = 0.0f;
                 if (ANY) {
@@ -779,7 +788,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             ++iter;
         } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & period) != 0);
     }
-    if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0));
+    if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0), l0store ? (uint32_t)q.shL[ray_i] : 0u);
     if (COUNT) {
         if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
@@ -1018,10 +1027,10 @@ template <int STATS, int MODE>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
     traceQueue<false, STATS, MODE>(sc, root_ref, q, level, stack_entries, -1, 0u);
 }
-template <int STATS, int MODE>
+template <int STATS, int MODE, bool L0 = false>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries, int round,
                                                      uint32_t budget) {
-    traceQueue<true, STATS, MODE>(sc, root_ref, q, level, stack_entries, round, budget);
+    traceQueue<true, STATS, MODE, L0>(sc, root_ref, q, level, stack_entries, round, budget);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1431,6 +1440,32 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     }
 }
 
+// Level-0 shadow results that k_any stored instead of adding (RtQueues::occ0): one lane per sample adds the radiance of
+// its unoccluded level-0 shadow rays to the sample's accumulator.  Runs behind k_any(0) and its split rounds, before
+// anything of level 1 touches the accumulators; no other kernel is active, so plain read-modify-write.
+__global__ __launch_bounds__(RT_BLOCK) void k_fold0(RtQueues q, uint32_t samples, int nlights) {
+    for (uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x; s < samples; s += gridDim.x * RT_BLOCK) {
+        unsigned long long ax = 0, ay = 0, az = 0;
+        bool any = false;
+        for (int l = 0; l < nlights; l++) {
+            const size_t at = (size_t)l * q.l0_stride + s;
+            if (q.occ0[at]) {
+                const float4 C = q.col0[at];
+                ax += (unsigned long long)rtToFixed(C.x);
+                ay += (unsigned long long)rtToFixed(C.y);
+                az += (unsigned long long)rtToFixed(C.z);
+                any = true;
+            }
+        }
+        if (any) {
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * s;
+            acc[0] += ax;
+            acc[1] += ay;
+            acc[2] += az;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // trace_ray's clamp per SAMPLE (main.cpp:232), mean over samples (:646), toneMapping (:240-256),
 // Image::setPixel truncation (Image.h:91-95).  One lane per pixel slot of the chunk; outputs are tile-major.
@@ -1588,7 +1623,11 @@ static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t r
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
     const uint32_t budget = ANY && q.split_cap ? (uint32_t)cfg.split_budget : 0u;
 #define RT_LAUNCHC(S, M) hipLaunchKernelGGL((k_closest<S, M>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
-#define RT_LAUNCHA(S, M, G, R, B) hipLaunchKernelGGL((k_any<S, M>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B)
+#define RT_LAUNCHA(S, M, G, R, B)                                                                                                       \
+    do {                                                                                                                                \
+        if (level == 0 && q.occ0) hipLaunchKernelGGL((k_any<S, M, true>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B); \
+        else hipLaunchKernelGGL((k_any<S, M, false>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B);       \
+    } while (0)
 #define RT_LAUNCHP(A, S) hipLaunchKernelGGL((k_packet<A, S>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, level)
 // (stats: 0 = plain, 1 = counters, 2 = counters + wave-time profile)
 #define RT_BY_STATS(CALL) do { if (stats >= 2) { CALL(2); } else if (stats == 1) { CALL(1); } else { CALL(0); } } while (0)
@@ -1650,6 +1689,9 @@ void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues 
         if (prof) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
         else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
     }
+}
+void rtLaunchFold0(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t samples, int nlights) {
+    hipLaunchKernelGGL(k_fold0, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, q, samples, nlights);
 }
 void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles) {

@@ -185,6 +185,13 @@ struct RtQueues {
     uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap;
+    // Level-0 shadow results without atomics (null = off): a sample has ONE level-0 hit, hence at most one level-0 shadow
+    // ray per light, so k_any can STORE the radiance of an unoccluded one at [light][sample] (col0, flag in occ0) and
+    // k_fold0 adds them to the accumulator afterwards, one lane per sample.  Same fixed-point sums, same bits; pays where
+    // most shadow rays are level-0 rays that reach their light (the L2 retires only ~75 G atomics per second).
+    uint8_t *occ0;             // [light][l0_stride] 1 = col0 holds a contribution; cleared per chunk
+    float4 *col0;              // [light][l0_stride]
+    uint32_t l0_stride;        // samples of the chunk
 };
 
 // Device counters.  Every hot counter owns a 128-byte line: returning atomics on one line serialise at the memory

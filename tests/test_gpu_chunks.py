@@ -55,3 +55,26 @@ def test_single_frame_flag_changes_no_bit():
     assert a["stats"]["chunks"] >= 2 and a["stats"]["chunk_retries"] == 0
     for x in (a, b):
         assert np.array_equal(x["rgb8"], ref["rgb8"]) and np.array_equal(x["primid"], ref["primid"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bunny", "sample"])
+def test_level0_shadow_results_stored_or_added_same_bits(name):
+    """RtQueues::occ0: where most shadow rays are level-0 rays, k_any stores the radiance of an unoccluded level-0 shadow ray
+    at [light][sample] and k_fold0 adds it to the accumulator, instead of three 64-bit atomics per ray.  Same integers."""
+    from raytracer_amd.renderer import Renderer
+    r = Renderer(0).set_scene(get_scene(name, False))
+    w, h, spp = 1280, 720, 16
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["RT_L0_STORE"] = mode
+        try:
+            r.render(w, h, spp=spp, want=())  # (the first frame after commit also measures the scene's fan-out)
+            out[mode] = r.render(w, h, spp=spp, collect_stats=1, want=("rgb8", "rgbf", "primid"))
+        finally:
+            del os.environ["RT_L0_STORE"]
+    for k in ("rgb8", "primid"):
+        assert np.array_equal(out["0"][k], out["1"][k]), k
+    assert np.array_equal(out["0"]["rgbf"].view(np.uint32), out["1"]["rgbf"].view(np.uint32))
+    for k in ("rays_closest", "rays_shadow", "shadow_zero", "shadow_unoccluded", "hits_shaded"):
+        assert out["0"]["stats"][k] == out["1"]["stats"][k], k
