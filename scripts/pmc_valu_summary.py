@@ -4,7 +4,7 @@ SIMDs' VALU issue capacity used.  Capacity: MI355X_MICROARCH.md gives 2 cycles p
 (4 for one wave alone) => 0.5 instructions per cycle per SIMD, 1024 SIMDs.  Writes DIR/pmc_valu.json, prints a table.
 The clock comes from the counters, not from a nominal figure: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time
 of the SAME pass (the pass's own kernel trace)."""
-import collections, csv, glob, json, os, sys
+import re, collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd._native import kernel_source_hash
 
@@ -15,7 +15,7 @@ SIMDS = 1024
 def key(name):
     full = name.split("(")[0].replace("void ", "")
     k = full.split("<")[0]
-    return "k_any_split" if k == "k_any" and full.rstrip().endswith(", 2>") else k
+    return "k_any_split" if k == "k_any" and re.match(r"k_any<\d+, 2\b", full) is not None else k
 
 
 def durations(sub):
