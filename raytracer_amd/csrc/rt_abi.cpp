@@ -405,6 +405,10 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     std::vector<uint32_t> hc(RT_CNT_WORDS, 0);
     size_t done = 0;            // tiles of this rank rendered so far
     bool force_worst = false;   // the chunk being repeated after an overflow
+    const size_t nlights = ctx->lights.size();
+    // level-0 shadow results stored instead of added (RtQueues::occ0, decided per chunk below): its buffers count
+    auto wantL0 = [&]() { return nlights > 0 && (l0_mode == 1 || (l0_mode < 0 && ctx->obs_valid && ctx->obs_l0_share >= 0.6)); };
+    auto l0Bytes = [&](size_t samples) { return wantL0() ? samples * nlights * (sizeof(float4) + 1) : (size_t)0; };
     struct Plan { size_t tiles, samples; QueueSizes z; bool optimistic; };
     auto planChunk = [&](size_t remaining, bool worst, Plan &pl) -> int {
         const bool single = (p->flags & RT_RENDER_SINGLE_FRAME) != 0;
@@ -423,11 +427,11 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
             // Worst-case queues may take 7/8 of it (deep bounce budgets need the room to fit at all); queues sized from
             // the observed fan-out stop at `ws_frac` (half by default, RT_WORKSPACE_FRACTION): larger chunks than that buy
             // ~1 % (profiles/r02_chunks.md) and the memory has other users (scene, outputs, torch, RCCL).
-            const size_t avail = free_b + ctx->ws_bytes;
+            const size_t avail = free_b + ctx->ws_bytes + ctx->d_occ0.n + ctx->d_col0.n * sizeof(float4);
             const size_t budget = pl.optimistic ? (size_t)((double)avail * ws_frac) : avail / 8 * 7;
             while (chunk_samples > per_tile) {
                 const QueueSizes z = queueSizes(ctx, chunk_samples, ray_fan, sh_fan, nl);
-                if (z.fits32 && z.bytes + z.bytes / 8 <= budget) break;  // (+ 1/8: the headroom a growing queue gets)
+                if (z.fits32 && z.bytes + z.bytes / 8 + l0Bytes(chunk_samples) <= budget) break;  // (+ 1/8: the headroom a growing queue gets)
                 chunk_samples = pl.optimistic ? chunk_samples / 8 * 7 : chunk_samples / 2;
             }
             if (single && pl.optimistic && ctx->q.ray_cap) {  // no growth inside a single frame: what the queues hold as they are
@@ -476,8 +480,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         // frame whose shadow rays mostly come from deeper levels hides its atomics behind the walks and would only pay for
         // the extra pass.  Either way the sums are the same integers.  RT_L0_STORE=0 / 1 forces the choice.
         RtQueues cq = ctx->q;
-        const size_t nlights = ctx->lights.size();
-        const bool l0 = nlights > 0 && (l0_mode == 1 || (l0_mode < 0 && ctx->obs_valid && ctx->obs_l0_share >= 0.6));
+        const bool l0 = wantL0();
         if (l0) {
             if (ctx->d_occ0.alloc(samples * nlights) || ctx->d_col0.alloc(samples * nlights)) return 1;
             cq.occ0 = ctx->d_occ0.p;
@@ -541,7 +544,13 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         // seconds (hipFree + hipMalloc), so it is done here, at the end of the frame that found out, not inside the next
         // one.  A no-op in steady state; a failure is not this frame's (the next call sizes its workspace anew).
         Plan pl;
-        if (!planChunk((size_t)n_local, false, pl)) (void)ensureWorkspace(ctx, pl.samples, pl.z);
+        if (!planChunk((size_t)n_local, false, pl)) {
+            (void)ensureWorkspace(ctx, pl.samples, pl.z);
+            if (wantL0()) {
+                (void)ctx->d_occ0.alloc(pl.samples * nlights);
+                (void)ctx->d_col0.alloc(pl.samples * nlights);
+            }
+        }
     }
     double cls[6] = {0, 0, 0, 0, 0, 0};
     kt.collect(cls);
