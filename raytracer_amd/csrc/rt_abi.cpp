@@ -520,6 +520,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
                 double s0 = (double)hc[RT_CNT_SHADOW(0)] - 0.0, sall = 0.0;
                 for (int d = 0; d <= p->max_depth && d < 16; d++) sall += (double)hc[RT_CNT_SHADOW(d)];
                 ctx->obs_l0_share = sall > 0 ? s0 / sall : 0.0;
+                if (getenv("RT_VERBOSE")) std::fprintf(stderr, "[rt] chunk of %zu samples: level-0 share of the shadow rays %.2f\n", samples, ctx->obs_l0_share);
             }
             if (!ctx->obs_valid) ctx->obs_ray = ctx->obs_sh = 0.0;
             ctx->obs_ray = std::max(ctx->obs_ray, r);
