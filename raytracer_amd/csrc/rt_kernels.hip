@@ -1006,12 +1006,20 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t 
     // STATS: [0] packets, [1] node steps, [2] lanes interested in a child per node step, [3] triangle steps, [4] live
     // lanes per triangle step, [5] packets over budget, [6] octant groups walked, [7] rays handed to the lane kernel
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // Guided batches: a wave walks the packets of its batch one after the other (~0.15 ms each), so the last batches of a
+    // launch keep a few waves busy for RT_PACKET_BATCH packets while the chip idles (1.4 ms per launch).  Towards the end
+    // of the queue a wave takes fewer packets per fetch; how far the queue has got is known from its previous fetch.
+    const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64);
+    uint32_t seen = 0;
     for (;;) {
+        const uint32_t left = n > seen ? n - seen : 0u;
+        const uint32_t want = 64u * min((uint32_t)RT_PACKET_BATCH, max(1u, left / (128u * nwaves)));
         uint32_t base = 0;
-        if (laneId() == 0) base = atomicAdd(work, 64u * RT_PACKET_BATCH);
+        if (laneId() == 0) base = atomicAdd(work, want);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= n) break;
-        const uint32_t end = min(base + 64u * RT_PACKET_BATCH, n);
+        seen = base + want;
+        const uint32_t end = min(base + want, n);
         for (uint32_t pb = base; pb < end; pb += 64u) {
             if (STATS) prof[0]++;
             tracePacket<ANY, STATS>(sc, an, root_ref, q, level, pb, n, prof);
