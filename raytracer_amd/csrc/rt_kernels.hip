@@ -504,11 +504,13 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     uint32_t *items_out_count = q.counters + RT_CNT_SPLIT(level, round + 1);
     uint32_t iter = 0;                                     // wave iterations of the walk loop so far (uniform)
     // the wave passes the top of its outer loop (where long lanes are looked for) at least every period + 1 iterations
-    const uint32_t period = (SPLIT && budget && budget < 1024u) ? budget - 1u : 1023u;  // budget is a power of two
+    const uint32_t period = (budget && budget < 1024u) ? budget - 1u : 1023u;  // budget is a power of two
     bool can_export = true;                                // uniform: cleared when the round's item buffer is full
     bool occl = false;                                     // SPLIT: the finished item found a hit
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;  // wave-uniform
+    uint32_t part_seen = 0;                                // how far the current part had got at this wave's last fetch
+    const uint32_t tail_len = gridDim.x * (RT_BLOCK / 64) / PARTS * batch;  // one full batch per wave of the part
     bool more = true;                      // wave-uniform: the queue may still hold unclaimed rays
     bool has = false;
     uint32_t ray_i = 0, sample = 0;
@@ -611,17 +613,22 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
         const unsigned long long idle2 = __ballot(!has);
         if (idle2 && more) {
             while (pool_next >= pool_end && parts_done < PARTS) {
-                uint32_t base = 0;
-                if (laneId() == 0) base = atomicAdd(PARTS > 1 ? work_parts + part * RT_CNT_STRIDE : work, batch);
-                base = __builtin_amdgcn_readfirstlane(base);
                 const uint32_t lo = part * part_len, hi = min(lo + part_len, n);
+                // (two batch sizes: one generation of rays once the part is nearly used up -- as far as this wave knows from
+                // its previous fetch -- so that a launch does not end with a few waves walking 256 rays each)
+                const uint32_t want = lo + part_seen + tail_len >= hi ? 64u : batch;
+                uint32_t base = 0;
+                if (laneId() == 0) base = atomicAdd(PARTS > 1 ? work_parts + part * RT_CNT_STRIDE : work, want);
+                base = __builtin_amdgcn_readfirstlane(base);
                 if (lo + base < hi && lo < n) {
                     pool_next = lo + base;
-                    pool_end = min(pool_next + batch, hi);
+                    pool_end = min(pool_next + want, hi);
                     pool_base = pool_next;
+                    part_seen = base + want;
                 } else {  // this part is used up: on to the next
                     part = part + 1 == PARTS ? 0u : part + 1;
                     parts_done++;
+                    part_seen = 0;
                 }
             }
             if (parts_done >= PARTS) more = false;
