@@ -57,3 +57,20 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert "librt_oracle" not in txt and "oracle/" not in txt.replace("oracle/ref_harness.cpp", "").replace("oracle/rt_oracle.cpp", ""), f
+
+
+def test_ctypes_mirrors_have_the_header_sizes(tmp_path):
+    """rt_stats & co. are filled by the library through a pointer: a ctypes mirror that is shorter than the C struct would be
+    written past its end.  The sizes come from the header itself, compiled with gcc (host code, no GPU)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        return  # (no compiler: nothing to compare with)
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rt_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(rt_stats), '
+                   'sizeof(rt_commit_stats), sizeof(rt_render_params), sizeof(rt_camera), sizeof(rt_material), sizeof(rt_hit)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(N.REPO_DIR, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    want = [ctypes.sizeof(t) for t in (N.Stats, N.CommitStats, N.RenderParams, N.Camera, N.Material, N.Hit)]
+    assert got == want
