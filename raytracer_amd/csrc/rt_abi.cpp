@@ -93,9 +93,6 @@ struct rt_context {
     DevBuf<RtNode4> d_records;  // BVH nodes, then the triangle records (rt_types.h)
     DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part
     DevBuf<RtNodeP> d_nodes_p;  // float-box form of the nodes (packet kernels)
-    DevBuf<uint32_t> d_resid;   // queue indices of the rays the packet kernels hand to the per-lane kernels
-    DevBuf<uint32_t> d_general; // queue indices of the hits the fast k_shade leaves to the general one
-    DevBuf<uint2> d_split[2];   // work items of split any-hit walks (rt_kernels.hip), ping-pong by round
     DevBuf<RtTriShade> d_shade;
     DevBuf<RtSphere> d_spheres;
     DevBuf<RtPlane> d_planes;
@@ -104,23 +101,17 @@ struct rt_context {
     DevBuf<RtLight> d_lights;
     DevBuf<uint8_t> d_bmp[4];
     RtSceneDev dev{};
-    // wavefront workspace (sized for one chunk, reused across calls)
-    size_t ws_samples = 0, ws_bytes = 0;
-    // Fan-out observed on this scene: queue entries per primary sample at the fullest level, maximum over the chunks
-    // rendered since rt_commit (rays; shadow rays over all lights), and the deepest bounce budget it was seen at.
-    // Chunks are sized from it once it exists (renderTiles); reset by rt_commit.
+    // Wavefront workspace: ONE arena, carved anew for every frame (carveQueues).  It is allocated once -- the whole budget
+    // (RT_WORKSPACE_GB, 24 GiB by default) for a frame that needs more than one chunk, what the frame needs otherwise -- and
+    // grows only when a later call cannot fit a single tile into it or asks for a chunk size of its own.
+    DevBuf<unsigned char> d_arena;
+    // Fan-out observed on this scene since rt_commit: queue entries per primary sample of a chunk that one iteration of the
+    // pipeline holds in steady state (all levels together; shadow rays over all lights), without the slab slack, and the
+    // deepest bounce budget it was seen at.  Frames are planned from it once it exists (planFrame); reset by rt_commit.
     bool obs_valid = false;
     double obs_ray = 0.0, obs_sh = 0.0;
-    double obs_l0_share = 0.0;  // share of the last chunk's shadow rays that were level-0 rays
+    double obs_l0_share = 0.0;  // share of the last frame's shadow rays that were level-0 rays
     int obs_depth = -1;
-    DevBuf<float4> d_rayA[2], d_rayB[2], d_shA, d_shC;
-    DevBuf<uint8_t> d_shL, d_occ0;  // d_occ0 / d_col0: level-0 shadow results stored per [light][sample] (RtQueues::occ0)
-    DevBuf<float4> d_col0;
-    DevBuf<float> d_rayR[2];
-    DevBuf<float2> d_hits;
-    DevBuf<long long> d_accum;
-    DevBuf<uint32_t> d_counters;
-    RtQueues q{};
     // the library's static scratch on this context's device (rt_render_tiles_static); resolved at rt_create
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -137,443 +128,10 @@ int bind(rt_context *ctx) {
     return 0;
 }
 
-// queue entries one chunk of `samples` primary samples can need: worst case of the deepest level, plus what k_shade's
-// wave-private slabs may leave unused (one partly filled slab per wave and queue, one slot per slab where a
-// reflection/refraction pair met its end)
-struct QueueSizes {
-    size_t ray_cap, sh_cap, bytes;
-    bool fits32;
-};
-// ray_fan / sh_fan: queue entries per primary sample at the fullest level (rays; shadow rays over all lights)
-QueueSizes queueSizes(const rt_context *ctx, size_t samples, double ray_fan, double sh_fan, int nl) {
-    QueueSizes z;
-    const size_t waves = (size_t)rtShadeWaves(ctx->cfg);
-    const size_t rays = (size_t)std::ceil((double)samples * ray_fan), shadows = (size_t)std::ceil((double)samples * sh_fan);
-    // (x 2: the fast and the general instance of k_shade both reserve slabs)
-    z.ray_cap = rays + 2 * waves * RT_SLAB_MAX + rays / 64 + 128;
-    z.sh_cap = shadows + 2 * waves * nl * RT_SLAB_MAX;
-    z.fits32 = z.ray_cap < (1ull << 32) && z.sh_cap < (1ull << 32);
-    z.bytes = z.ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + z.sh_cap * 33 + samples * 24 + std::max(z.sh_cap, z.ray_cap) * 4;
-    return z;
-}
-QueueSizes queueSizes(const rt_context *ctx, size_t samples, int fanout, int nl) {  // worst case
-    return queueSizes(ctx, samples, (double)fanout, (double)fanout * nl, nl);
-}
-
-// rays of the deepest level per primary sample, worst case: every hit spawns a reflection/refraction pair (main.cpp:148-205)
-int worstFanout(int max_depth) { return 1 << std::min(std::max(max_depth, 0), 15); }
-
 double nowMs();
-int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z);
-int ensureWorkspace(rt_context *ctx, size_t samples, int max_depth, int n_lights) {
-    return ensureWorkspace(ctx, samples, queueSizes(ctx, samples, worstFanout(max_depth), std::max(n_lights, 1)));
-}
-int ensureWorkspace(rt_context *ctx, size_t samples, const QueueSizes &z) {
-    if (!z.fits32) return fail("chunk too large: queue capacity exceeds 2^32 entries");
-    if (samples <= ctx->ws_samples && z.ray_cap <= ctx->q.ray_cap && z.sh_cap <= ctx->q.shadow_cap) return 0;
-    // grow: capacities only ever go up (a later call with fewer samples but more bounces keeps the larger of each)
-    samples = std::max(samples, ctx->ws_samples);
-    // a queue that must grow grows by an eighth more than asked (capped below 2^32): the fan-out a scene shows moves by a
-    // few per cent from frame to frame, and every growth is a hipFree + hipMalloc of tens of GB
-    auto grown = [](size_t want, size_t have) -> size_t {
-        if (want <= have) return have;
-        return have ? std::min<size_t>(want + want / 8, 0xFFFFFFFEull) : want;
-    };
-    const size_t ray_cap = grown(z.ray_cap, ctx->q.ray_cap), sh_cap = grown(z.sh_cap, ctx->q.shadow_cap);
-    // DevBuf::alloc frees before it allocates: after a failed grow some buffers are new, some are gone.  The
-    // workspace is then declared empty (sizes 0, queue pointers null), so that no later call takes the early return
-    // above and launches kernels on freed memory; the next call allocates from scratch.
-    auto grow = [&]() -> int {
-        for (int k = 0; k < 2; k++) {
-            if (ctx->d_rayA[k].alloc(ray_cap) || ctx->d_rayB[k].alloc(ray_cap) || ctx->d_rayR[k].alloc(ray_cap)) return 1;
-        }
-        if (ctx->d_hits.alloc(ray_cap + 1)) return 1;
-        if (ctx->d_shA.alloc(sh_cap) || ctx->d_shC.alloc(sh_cap) || ctx->d_shL.alloc(sh_cap)) return 1;
-        if (ctx->d_accum.alloc(samples * 3)) return 1;
-        if (ctx->d_counters.alloc(RT_CNT_WORDS)) return 1;
-        if (ctx->d_resid.alloc(std::max(sh_cap, ray_cap))) return 1;
-        if (ctx->d_general.alloc(ray_cap)) return 1;
-        return 0;
-    };
-    const double t_grow0 = nowMs();
-    size_t split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
-    if (const char *e = getenv("RT_SPLIT_CAP")) split_cap = (size_t)std::max(64, atoi(e));  // (test knob: forces the no-room path)
-    if (grow() || ctx->d_split[0].alloc(split_cap) || ctx->d_split[1].alloc(split_cap)) {
-        const std::string why = g_err;
-        for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); ctx->d_split[k].release(); }
-        ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_occ0.release(); ctx->d_col0.release(); ctx->d_accum.release(); ctx->d_resid.release(); ctx->d_general.release();
-        ctx->ws_samples = 0;
-        ctx->ws_bytes = 0;
-        ctx->q = RtQueues{};
-        ctx->q.spill = ctx->d_spill.p;
-        return fail("workspace allocation failed (workspace released): " + why);
-    }
-    ctx->ws_bytes = ray_cap * (2 * (16 + 16 + 4) + 8 + 4) + sh_cap * 33 + samples * 24 + std::max(sh_cap, ray_cap) * 4 + 2 * split_cap * sizeof(uint2);
-    ctx->ws_samples = samples;
-    if (getenv("RT_VERBOSE"))
-        std::fprintf(stderr, "[rt] workspace grown to %zu samples, %zu ray slots, %zu shadow slots (%.1f GB) in %.0f ms\n", samples, ray_cap,
-                     sh_cap, (double)ctx->ws_bytes / 1e9, nowMs() - t_grow0);
-    RtQueues &q = ctx->q;
-    for (int k = 0; k < 2; k++) {
-        q.rayA[k] = ctx->d_rayA[k].p;
-        q.rayB[k] = ctx->d_rayB[k].p;
-        q.rayR[k] = ctx->d_rayR[k].p;
-    }
-    q.hits = ctx->d_hits.p;
-    q.shA = ctx->d_shA.p;
-    q.shC = ctx->d_shC.p;
-    q.shL = ctx->d_shL.p;
-    q.occ0 = nullptr;  // (set per chunk by renderTiles)
-    q.col0 = nullptr;
-    q.l0_stride = 0;
-    q.accum = ctx->d_accum.p;
-    q.counters = ctx->d_counters.p;
-    q.spill = ctx->d_spill.p;
-    q.resid = ctx->d_resid.p;
-    q.general = ctx->d_general.p;
-    q.split[0] = ctx->d_split[0].p;
-    q.split[1] = ctx->d_split[1].p;
-    q.split_cap = (uint32_t)split_cap;
-    q.ray_cap = (uint32_t)ray_cap;
-    q.shadow_cap = (uint32_t)sh_cap;
-    return 0;
-}
 
-struct KernelTimer {  // optional per-kernel-class timing with HIP events on the launch stream
-    bool on = false;
-    hipStream_t stream = nullptr;
-    struct Span { hipEvent_t a, b; int cls; };
-    std::vector<Span> spans;
-    void begin(int cls) {
-        if (!on) return;
-        Span s;
-        (void)hipEventCreate(&s.a);
-        (void)hipEventCreate(&s.b);
-        s.cls = cls;
-        (void)hipEventRecord(s.a, stream);
-        spans.push_back(s);
-    }
-    void end() {
-        if (!on) return;
-        (void)hipEventRecord(spans.back().b, stream);
-    }
-    void collect(double *ms /*[6]*/) {
-        for (Span &s : spans) {
-            float t = 0;
-            (void)hipEventElapsedTime(&t, s.a, s.b);
-            ms[s.cls] += t;
-            (void)hipEventDestroy(s.a);
-            (void)hipEventDestroy(s.b);
-        }
-        spans.clear();
-    }
-};
-
-void addCounters(rt_stats *st, const uint32_t *c, int max_depth) {
-    for (int d = 0; d <= max_depth && d < 16; d++) {
-        st->rays_closest += c[RT_CNT_RAYS(d)];
-        st->rays_shadow += c[RT_CNT_SHADOW(d)];
-    }
-    auto u64at = [&](int w) { return ((uint64_t)c[w + 1] << 32) | c[w]; };
-    st->rays_closest -= c[RT_CNT_INVALID];  // slots of pixels outside the image and unused slab slots are not rays
-    st->rays_shadow -= c[RT_CNT_SHADOW_HOLES];
-    st->shadow_culled += c[RT_CNT_CULLED];
-    st->shadow_zero += c[RT_CNT_ZERO];
-    st->shadow_unoccluded += u64at(RT_CNT_UNOCCLUDED);
-    for (int d = 0; d <= max_depth && d < 16; d++)
-        for (int r = 0; r <= RT_SPLIT_ROUNDS; r++) st->split_items += c[RT_CNT_SPLIT(d, r)];
-    st->hits_shaded += c[RT_CNT_SHADED];
-    st->queue_overflow += c[RT_CNT_OVERFLOW];
-    st->nodes_visited += u64at(RT_CNT_NODES);
-    st->tris_tested += u64at(RT_CNT_NODES + 2);
-    st->nodes_visited_any += u64at(RT_CNT_ANY_NODES);
-    st->max_walk_closest = std::max<uint64_t>(st->max_walk_closest, c[RT_CNT_NODES + 4]);
-    st->max_walk_any = std::max<uint64_t>(st->max_walk_any, c[RT_CNT_ANY_NODES + 4]);
-    st->tris_tested_any += u64at(RT_CNT_ANY_NODES + 2);
-    for (int k = 0; k < 10; k++) {
-        st->prof_closest[k] += u64at(RT_CNT_PROF_CLOSEST + 2 * k);
-        st->prof_any[k] += u64at(RT_CNT_PROF_ANY + 2 * k);
-    }
-    for (int k = 0; k < 6; k++) st->prof_shade[k] += u64at(RT_CNT_PROF_SHADE + 2 * k);
-    for (int k = 0; k < 8; k++) {
-        st->prof_packet_closest[k] += u64at(RT_CNT_PROF_PACKET_CLOSEST + 2 * k);
-        st->prof_packet_any[k] += u64at(RT_CNT_PROF_PACKET_ANY + 2 * k);
-    }
-}
-
-// levels 0..max_depth of one chunk whose level-0 queue has already been filled
-void runLevels(rt_context *ctx, const RtQueues &q, const RtLaunchCfg &cfg, int max_depth, int spp, uint32_t tile0, uint32_t *primid_tiles,
-               int stats, KernelTimer &kt, rt_stats *st, uint64_t level0_rays, bool level0_traced = false) {
-    for (int level = 0; level <= max_depth; level++) {
-        if (!(level == 0 && level0_traced)) {  // each level's queue is claimed once (dynamic fetch counters)
-            if (rtLevelUsesPackets(cfg, level, false)) {
-                kt.begin(5);
-                rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats, 1);
-                kt.end();
-            }
-            kt.begin(1);
-            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats, 2);
-            kt.end();
-        }
-        kt.begin(2);
-        rtLaunchShade(cfg, ctx->dev, q, level, max_depth, spp, tile0, primid_tiles, stats >= 2, level0_rays << level);
-        kt.end();
-        kt.begin(3);
-        rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, level, stats);
-        if (level == 0 && q.occ0) rtLaunchFold0(cfg, q, (uint32_t)level0_rays, (int)ctx->lights.size());
-        kt.end();
-        if (st) {  // launches that walk a level's queue (what a kernel trace lists as k_closest<.., 0> / k_any<.., 0>): the
-                   // hand-over launch behind a packet level and the split rounds are not counted
-            if (!(level == 0 && level0_traced) && !rtLevelUsesPackets(cfg, level, false)) st->launches_closest++;
-            if (!rtLevelUsesPackets(cfg, level, true)) st->launches_any++;
-        }
-    }
-}
-
-// parameter checks + camera / image constants of the tile loop (main.cpp:561-563), shared by the render entry points
-int makeFrame(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, RtFrameDev &f, int &world) {
-    if (!ctx->committed) return fail("rt_commit has not been called");
-    if (p->width <= 0 || p->height <= 0 || p->spp <= 0 || p->max_depth < 0 || p->max_depth > 15)
-        return fail("bad render parameters (width/height/spp > 0, 0 <= max_depth <= 15)");
-    world = p->tile_world > 0 ? p->tile_world : 1;
-    if (p->tile_rank < 0 || p->tile_rank >= world) return fail("tile_rank out of range");
-    const bool table = p->jitter_mode == RT_JITTER_TABLE || (p->jitter_mode == RT_JITTER_AUTO && p->spp == 4);
-    if (table && p->spp != 4) return fail("RT_JITTER_TABLE requires spp == 4 (reference jitterMatrix, main.cpp:601-606)");
-    f = RtFrameDev{};
-    std::memcpy(f.origin, cam->origin, sizeof f.origin);
-    std::memcpy(f.rot, cam->rot, sizeof f.rot);
-    f.dz = cam->dz;
-    // main.cpp:561-563: computed in double, stored as float
-    const float fov = cam->fov_deg;
-    const float s = 2 * tan(0.5 * fov / 180 * M_PI) / p->width;
-    f.s = s;
-    f.X = -s * p->width / 2;
-    f.Y = s * p->height / 2;
-    f.width = p->width;
-    f.height = p->height;
-    f.spp = p->spp;
-    f.tiles_x = (p->width + RT_TILE - 1) / RT_TILE;
-    f.tile_rank = p->tile_rank;
-    f.tile_world = world;
-    f.use_table = table ? 1 : 0;
-    f.seed = p->seed;
-    return 0;
-}
-
-int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *d_rgb8, float *d_rgbf,
-                uint32_t *d_primid, hipStream_t stream, rt_stats *stats) {
-    RtFrameDev f{};
-    int world = 1;
-    if (makeFrame(ctx, cam, p, f, world)) return 1;
-    if (bind(ctx)) return 1;
-
-    int64_t n_local = 0, n_total = 0;
-    rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, &n_total);
-    const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
-    if (per_tile > RT_SAMPLE_MASK) return fail("spp too large for one tile per chunk");
-    const int fo = worstFanout(p->max_depth), nl = std::max<int>(1, (int)ctx->lights.size());
-
-    RtLaunchCfg cfg = ctx->cfg;
-    cfg.stream = stream;
-    const int stats_on = (p->collect_stats & 4) ? 2 : (p->collect_stats & 1) ? 1 : 0;  // counters / + wave-time profile
-    KernelTimer kt;
-    kt.on = (p->collect_stats & 2) != 0;
-    kt.stream = stream;
-    rt_stats local{};
-    rt_stats *st = stats ? stats : &local;
-    std::memset(st, 0, sizeof *st);
-
-    hipEvent_t ev0, ev1;
-    HIPOK(hipEventCreate(&ev0));
-    HIPOK(hipEventCreate(&ev1));
-    bool started = false;  // ev0 is recorded once the first chunk's workspace exists: ms_total is GPU time, not hipMalloc time
-    // Chunks of whole tiles.  Large chunks are faster (deep levels hold few rays, and every launch ends with its longest
-    // ray: 8 chunks of 64 Mi samples cost 7 % more than 2 of 265 M on the 4K / 64 spp frame), but a chunk's queues must
-    // hold its fullest level, and the WORST case (every hit spawns a pair, every light faces every hit: 2^depth rays and
-    // 2^depth x lights shadow rays per sample) is 5-20 x what scenes produce.  So: the first chunk after rt_commit is
-    // sized for the worst case (64 Mi samples, halved until it fits 32-bit indices and the free memory); its counters
-    // give the fan-out this scene really has, and later chunks -- of this frame and of the following ones -- are sized
-    // for 1.5 x the largest fan-out seen so far.  A chunk that overflows its queues after all (the kernels drop and
-    // count what does not fit; nothing is written out of bounds) is rendered again at worst-case size: outputs are only
-    // written by a chunk's last kernels and the accumulators are initialised by its first, so a repeat is clean.
-    // A caller-given chunk size is taken as is, with worst-case queues.
-    int l0_mode = -1;  // level-0 shadow results stored instead of added: -1 = where it pays (below), 0 = never, 1 = always
-    if (const char *e = getenv("RT_L0_STORE")) l0_mode = atoi(e) != 0 ? 1 : 0;
-    double margin = 1.5, ws_frac = 0.5;
-    if (const char *e = getenv("RT_CHUNK_MARGIN")) margin = atof(e);  // (test knob: < 1 forces the overflow-and-repeat path)
-    if (const char *e = getenv("RT_WORKSPACE_FRACTION")) ws_frac = std::min(0.875, std::max(0.05, atof(e)));
-    std::vector<uint32_t> hc(RT_CNT_WORDS, 0);
-    size_t done = 0;            // tiles of this rank rendered so far
-    bool force_worst = false;   // the chunk being repeated after an overflow
-    const size_t nlights = ctx->lights.size();
-    // level-0 shadow results stored instead of added (RtQueues::occ0, decided per chunk below): its buffers count
-    auto wantL0 = [&]() { return nlights > 0 && (l0_mode == 1 || (l0_mode < 0 && ctx->obs_valid && ctx->obs_l0_share >= 0.6)); };
-    auto l0Bytes = [&](size_t samples) { return wantL0() ? samples * nlights * (sizeof(float4) + 1) : (size_t)0; };
-    struct Plan { size_t tiles, samples; QueueSizes z; bool optimistic; };
-    auto planChunk = [&](size_t remaining, bool worst, Plan &pl) -> int {
-        const bool single = (p->flags & RT_RENDER_SINGLE_FRAME) != 0;
-        pl.optimistic = p->chunk_samples <= 0 && !worst && ctx->obs_valid && p->max_depth <= ctx->obs_depth;
-        const double ray_fan = pl.optimistic ? std::min((double)fo, std::max(1.0, margin * ctx->obs_ray)) : (double)fo;
-        const double sh_fan = pl.optimistic ? std::min((double)fo * nl, std::max(1.0, margin * ctx->obs_sh)) : (double)fo * nl;
-        // (a single frame keeps its worst-case first chunk small: that chunk's queues are all it will ever allocate)
-        size_t chunk_samples = p->chunk_samples > 0 ? (size_t)p->chunk_samples
-                               : pl.optimistic ? (size_t)RT_SAMPLE_MASK : (size_t)1 << (single ? 24 : 26);
-        chunk_samples = std::min<size_t>(std::min<size_t>(chunk_samples, RT_SAMPLE_MASK), remaining * per_tile);
-        if (p->chunk_samples <= 0) {
-            // what fits 32-bit indices and 7/8 of the memory that is FREE on this device (torch, RCCL or other contexts
-            // may hold part of the HBM) plus what this context's workspace already holds
-            size_t free_b = 0, total_b = 0;
-            HIPOK(hipMemGetInfo(&free_b, &total_b));
-            // Worst-case queues may take 7/8 of it (deep bounce budgets need the room to fit at all); queues sized from
-            // the observed fan-out stop at `ws_frac` (half by default, RT_WORKSPACE_FRACTION): larger chunks than that buy
-            // ~1 % (profiles/r02_chunks.md) and the memory has other users (scene, outputs, torch, RCCL).
-            const size_t avail = free_b + ctx->ws_bytes + ctx->d_occ0.n + ctx->d_col0.n * sizeof(float4);
-            const size_t budget = pl.optimistic ? (size_t)((double)avail * ws_frac) : avail / 8 * 7;
-            while (chunk_samples > per_tile) {
-                const QueueSizes z = queueSizes(ctx, chunk_samples, ray_fan, sh_fan, nl);
-                if (z.fits32 && z.bytes + z.bytes / 8 + l0Bytes(chunk_samples) <= budget) break;  // (+ 1/8: the headroom a growing queue gets)
-                chunk_samples = pl.optimistic ? chunk_samples / 8 * 7 : chunk_samples / 2;
-            }
-            if (single && pl.optimistic && ctx->q.ray_cap) {  // no growth inside a single frame: what the queues hold as they are
-                while (chunk_samples > per_tile) {
-                    const QueueSizes z = queueSizes(ctx, chunk_samples, ray_fan, sh_fan, nl);
-                    if (z.ray_cap <= ctx->q.ray_cap && z.sh_cap <= ctx->q.shadow_cap) break;
-                    chunk_samples = chunk_samples / 8 * 7;
-                }
-            }
-        }
-        pl.tiles = std::min(std::max<size_t>(1, chunk_samples / per_tile), remaining);
-        {  // equal chunks over what is left: no small straggler at the end of the frame
-            const size_t nc = (remaining + pl.tiles - 1) / pl.tiles;
-            pl.tiles = (remaining + nc - 1) / nc;
-        }
-        pl.samples = pl.tiles * per_tile;
-        pl.z = queueSizes(ctx, pl.samples, ray_fan, sh_fan, nl);
-        return 0;
-    };
-    while (done < (size_t)n_local) {
-        Plan pl;
-        if (planChunk((size_t)n_local - done, force_worst, pl)) return 1;
-        const bool optimistic = pl.optimistic;
-        const size_t chunk_tiles = pl.tiles, samples = pl.samples;
-        QueueSizes need = pl.z;
-        size_t need_samples = samples;
-        if (optimistic && !(p->flags & RT_RENDER_SINGLE_FRAME) && (size_t)n_local > chunk_tiles) {
-            // queues that must grow now grow to what a repeat of the WHOLE frame will want: one reallocation, not two
-            Plan whole;
-            if (planChunk((size_t)n_local, false, whole)) return 1;
-            need.ray_cap = std::max(need.ray_cap, whole.z.ray_cap);
-            need.sh_cap = std::max(need.sh_cap, whole.z.sh_cap);
-            need.fits32 = need.fits32 && whole.z.fits32;
-            need_samples = std::max(need_samples, whole.samples);
-        }
-        if (ensureWorkspace(ctx, need_samples, need)) return 1;
-        if (!started) {
-            HIPOK(hipEventRecord(ev0, stream));
-            if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
-            started = true;
-        }
-        const uint32_t tile0 = (uint32_t)done, ntiles = (uint32_t)chunk_tiles;
-        const rt_stats before = *st;
-        // Level-0 shadow results stored instead of added (RtQueues::occ0) where most of the scene's shadow rays are
-        // level-0 rays: their three 64-bit atomics each are then what bounds k_any (bunny scene: 88 -> 27 ms), while a
-        // frame whose shadow rays mostly come from deeper levels hides its atomics behind the walks and would only pay for
-        // the extra pass.  Either way the sums are the same integers.  RT_L0_STORE=0 / 1 forces the choice.
-        RtQueues cq = ctx->q;
-        const bool l0 = wantL0();
-        if (l0) {
-            if (ctx->d_occ0.alloc(samples * nlights) || ctx->d_col0.alloc(samples * nlights)) return 1;
-            cq.occ0 = ctx->d_occ0.p;
-            cq.col0 = ctx->d_col0.p;
-            cq.l0_stride = (uint32_t)samples;
-            HIPOK(hipMemsetAsync(cq.occ0, 0, samples * nlights, stream));
-        }
-        HIPOK(hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
-        // (the sample accumulators need no clearing: level-0 k_shade stores every slot of the chunk)
-        kt.begin(0);
-        rtLaunchGenPrimary(cfg, f, cq, tile0, ntiles);
-        kt.end();
-        runLevels(ctx, cq, cfg, p->max_depth, p->spp, tile0, d_primid, stats_on, kt, st, (uint64_t)samples);
-        kt.begin(4);
-        rtLaunchResolve(cfg, f, cq, tile0, ntiles, d_rgb8, d_rgbf);
-        kt.end();
-        HIPOK(hipMemcpyAsync(hc.data(), ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIPOK(hipStreamSynchronize(stream));
-        HIPOK(hipGetLastError());
-        if (hc[RT_CNT_OVERFLOW] && optimistic) {  // the scene out-grew what was seen so far: again, sized for the worst case
-            *st = before;  // (launch counts of the discarded attempt)
-            st->chunks++;
-            st->chunk_retries++;
-            ctx->obs_valid = false;
-            force_worst = true;
-            continue;
-        }
-        st->chunks++;
-        addCounters(st, hc.data(), p->max_depth);
-        if (!hc[RT_CNT_OVERFLOW]) {
-            double r = 1.0, sh = 0.0;
-            for (int d = 0; d <= p->max_depth && d < 16; d++) {
-                r = std::max(r, (double)hc[RT_CNT_RAYS(d)] / (double)samples);
-                sh = std::max(sh, (double)hc[RT_CNT_SHADOW(d)] / (double)samples);
-            }
-            {
-                double s0 = (double)hc[RT_CNT_SHADOW(0)] - 0.0, sall = 0.0;
-                for (int d = 0; d <= p->max_depth && d < 16; d++) sall += (double)hc[RT_CNT_SHADOW(d)];
-                ctx->obs_l0_share = sall > 0 ? s0 / sall : 0.0;
-                if (getenv("RT_VERBOSE")) std::fprintf(stderr, "[rt] chunk of %zu samples: level-0 share of the shadow rays %.2f\n", samples, ctx->obs_l0_share);
-            }
-            if (!ctx->obs_valid) ctx->obs_ray = ctx->obs_sh = 0.0;
-            ctx->obs_ray = std::max(ctx->obs_ray, r);
-            ctx->obs_sh = std::max(ctx->obs_sh, sh);
-            ctx->obs_depth = ctx->obs_valid ? std::max(ctx->obs_depth, p->max_depth) : p->max_depth;
-            ctx->obs_valid = true;
-        }
-        force_worst = false;
-        done += chunk_tiles;
-    }
-    if (!started) HIPOK(hipEventRecord(ev0, stream));
-    HIPOK(hipEventRecord(ev1, stream));
-    HIPOK(hipStreamSynchronize(stream));
-    HIPOK(hipGetLastError());
-    float ms = 0;
-    HIPOK(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    st->ms_total = ms;
-    if (n_local > 0 && p->chunk_samples <= 0 && !(p->flags & RT_RENDER_SINGLE_FRAME)) {
-        // What a repeat of this frame will want, now that its fan-out is known: growing tens of GB of queues takes
-        // seconds (hipFree + hipMalloc), so it is done here, at the end of the frame that found out, not inside the next
-        // one.  A no-op in steady state; a failure is not this frame's (the next call sizes its workspace anew).
-        Plan pl;
-        if (!planChunk((size_t)n_local, false, pl)) {
-            (void)ensureWorkspace(ctx, pl.samples, pl.z);
-            if (wantL0()) {
-                (void)ctx->d_occ0.alloc(pl.samples * nlights);
-                (void)ctx->d_col0.alloc(pl.samples * nlights);
-            }
-        }
-    }
-    double cls[6] = {0, 0, 0, 0, 0, 0};
-    kt.collect(cls);
-    st->ms_gen = cls[0]; st->ms_closest = cls[1]; st->ms_shade = cls[2]; st->ms_any = cls[3]; st->ms_resolve = cls[4];
-    st->ms_packet = cls[5];
-    // primary samples = valid pixels of this rank's tiles x spp
-    {
-        uint64_t pix = 0;
-        const int tiles_x = f.tiles_x, tiles_y = (p->height + RT_TILE - 1) / RT_TILE;
-        for (int t = p->tile_rank; t < tiles_x * tiles_y; t += world) {
-            const int tx = t % tiles_x, ty = t / tiles_x;
-            pix += (uint64_t)std::min(RT_TILE, p->width - tx * RT_TILE) * std::min(RT_TILE, p->height - ty * RT_TILE);
-        }
-        st->primary_samples = pix * p->spp;
-    }
-    st->bvh_nodes = ctx->info.n_nodes;
-    st->bvh_depth = ctx->bvh.depth;
-    st->bvh_max_stack = ctx->bvh.max_stack;
-    st->n_triangles = ctx->info.n_triangles;
-    if (st->queue_overflow) return fail("wavefront queue overflow (" + std::to_string(st->queue_overflow) + " rays dropped)");
-    return 0;
-}
+// the frame pipeline: workspace carving, planning, the iteration loop (renderTiles, renderTilesStatic, traceBatch)
+#include "rt_frame.inl"
 
 }  // namespace
 
@@ -627,12 +185,9 @@ int rt_destroy(rt_context *ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_nodes_p.release(); ctx->d_resid.release(); ctx->d_split[0].release(); ctx->d_split[1].release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
+    ctx->d_records.release(); ctx->d_spill.release(); ctx->d_nodes_p.release(); ctx->d_arena.release(); ctx->d_shade.release(); ctx->d_spheres.release(); ctx->d_planes.release();
     ctx->d_materials.release(); ctx->d_objmat.release(); ctx->d_lights.release();
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
-    for (int k = 0; k < 2; k++) { ctx->d_rayA[k].release(); ctx->d_rayB[k].release(); ctx->d_rayR[k].release(); }
-    ctx->d_hits.release(); ctx->d_shA.release(); ctx->d_shC.release(); ctx->d_shL.release(); ctx->d_occ0.release(); ctx->d_col0.release(); ctx->d_accum.release(); ctx->d_general.release();
-    ctx->d_counters.release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -938,9 +493,8 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     const int entries = std::max(1, std::min(src->bvh.max_stack, RT_LDS_STACK));
     ctx->cfg.stack_entries = entries;
     ctx->cfg.packets = nn > 0 && src->bvh.max_stack <= 64;  // the packet walk keeps its stack in one VGPR (64 lanes)
-    if (const char *e = getenv("RT_PACKET_LEVELS")) {  // tuning knob: "<closest levels>,<shadow levels>"
-        int a = 1, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2) { ctx->cfg.packet_levels_closest = a; ctx->cfg.packet_levels_any = b; }
+    if (const char *e = getenv("RT_PACKET_LEVELS")) {  // tuning knob: 0 = primary rays walk per lane like every other ray
+        if (atoi(e) <= 0) ctx->cfg.packets = false;
     }
     ctx->dev.any_ordered = 0;  // tuning knob: shadow rays descend near-first (costs ~1 % on the competition scene)
     if (const char *e = getenv("RT_ANY_ORDERED")) ctx->dev.any_ordered = atoi(e) != 0;
@@ -957,7 +511,6 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     if (const char *e = getenv("RT_TRACE_BLOCKS")) ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(ctx->cfg.trace_blocks_per_cu, atoi(e)));  // (tuning knob)
     const size_t spill_entries = (size_t)std::max(0, src->bvh.max_stack - entries);
     if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;
-    ctx->q.spill = ctx->d_spill.p;
     HIPOK(hipDeviceSynchronize());
     ctx->commit_stats.ms_upload = nowMs() - t0;
     ctx->committed = true;
@@ -1011,95 +564,10 @@ int rt_assemble_tiles_device(rt_context *ctx, int32_t width, int32_t height, int
     return 0;
 }
 
-// ---- rt_render_tiles_static: the render loop on the library's static scratch, allocating nothing ----------------
-namespace {
-#define RT_STATIC_SHADE_BLOCKS 64   // k_shade grid of the static path: 256 waves, each owning (lights + 1) output slabs
-#define RT_STATIC_SLAB 64u          // slots per shadow slab (ray slabs: 128)
-#define RT_STATIC_SPLIT_CAP 65536u  // work items of split any-hit walks per round
-// carves the queues of `samples` primary samples out of [base, base + bytes); returns false if they do not fit
-bool carveStatic(unsigned char *base, size_t bytes, size_t samples, int fanout, int nl, uint32_t *spill, RtQueues &q) {
-    const size_t waves = (size_t)RT_STATIC_SHADE_BLOCKS * (RT_BLOCK / 64);
-    const size_t total = samples * (size_t)fanout;
-    const size_t ray_cap = total + 2 * waves * 128 + total / 64 + 128;        // as queueSizes(), with this path's slab sizes
-    const size_t sh_cap = total * nl + 2 * waves * nl * RT_STATIC_SLAB;
-    if (ray_cap >= (1ull << 31) || sh_cap >= (1ull << 31)) return false;
-    size_t off = 0;
-    auto take = [&](size_t n) -> void * {
-        void *p = base + off;
-        off += (n + 255) / 256 * 256;
-        return p;
-    };
-    q = RtQueues{};
-    q.counters = (uint32_t *)take(RT_CNT_WORDS * sizeof(uint32_t));
-    for (int k = 0; k < 2; k++) {
-        q.rayA[k] = (float4 *)take(ray_cap * sizeof(float4));
-        q.rayB[k] = (float4 *)take(ray_cap * sizeof(float4));
-        q.rayR[k] = (float *)take(ray_cap * sizeof(float));
-        q.split[k] = (uint2 *)take(RT_STATIC_SPLIT_CAP * sizeof(uint2));
-    }
-    q.hits = (float2 *)take((ray_cap + 1) * sizeof(float2));
-    q.shA = (float4 *)take(sh_cap * sizeof(float4));
-    q.shC = (float4 *)take(sh_cap * sizeof(float4));
-    q.shL = (uint8_t *)take(sh_cap);
-    q.occ0 = nullptr;
-    q.col0 = nullptr;
-    q.l0_stride = 0;
-    q.accum = (long long *)take(samples * 3 * sizeof(long long));
-    q.resid = (uint32_t *)take(std::max(sh_cap, ray_cap) * sizeof(uint32_t));
-    q.general = (uint32_t *)take(ray_cap * sizeof(uint32_t));
-    q.spill = spill;
-    q.ray_cap = (uint32_t)ray_cap;
-    q.shadow_cap = (uint32_t)sh_cap;
-    q.split_cap = RT_STATIC_SPLIT_CAP;
-    return off <= bytes;
-}
-}  // namespace
-
 int rt_render_tiles_static(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, void *d_rgb8, void *d_rgbf,
-                           void *d_primid, void *stream_) {
+                           void *d_primid, void *stream) {
     if (!ctx || !cam || !p) return fail("rt_render_tiles_static: NULL argument");
-    RtFrameDev f{};
-    int world = 1;
-    if (makeFrame(ctx, cam, p, f, world)) return 1;
-    if (bind(ctx)) return 1;
-    if (!ctx->scratch) return fail("rt_render_tiles_static: the static scratch was not resolved on this device");
-    hipStream_t stream = stream_ ? (hipStream_t)stream_ : ctx->stream;
-    int64_t n_local = 0;
-    rt_tile_counts(p->width, p->height, p->tile_rank, world, &n_local, nullptr);
-    const size_t per_tile = (size_t)RT_TILE_PIXELS * p->spp;
-    const int fo = worstFanout(p->max_depth), nl = std::max<int>(1, (int)ctx->lights.size());
-    // whole tiles per chunk: as many as the scratch holds (binary search on the carve)
-    RtQueues q{};
-    size_t lo = 0, hi = std::max<int64_t>(n_local, 1);
-    while (lo < hi) {
-        const size_t mid = (lo + hi + 1) / 2;
-        RtQueues t;
-        if (mid * per_tile <= RT_SAMPLE_MASK && carveStatic((unsigned char *)ctx->scratch, ctx->scratch_bytes, mid * per_tile, fo, nl, ctx->d_spill.p, t)) lo = mid;
-        else hi = mid - 1;
-    }
-    if (lo == 0)
-        return fail("rt_render_tiles_static: one 16x16 tile at " + std::to_string(p->spp) + " spp, depth " + std::to_string(p->max_depth) +
-                    " with " + std::to_string(nl) + " lights does not fit the " + std::to_string(ctx->scratch_bytes >> 20) +
-                    " MiB static scratch (lower spp or max_depth, or use rt_render_tiles_device)");
-    const size_t chunk_tiles = lo;
-    carveStatic((unsigned char *)ctx->scratch, ctx->scratch_bytes, chunk_tiles * per_tile, fo, nl, ctx->d_spill.p, q);
-    RtLaunchCfg cfg = ctx->cfg;
-    cfg.stream = stream;
-    cfg.shade_blocks = RT_STATIC_SHADE_BLOCKS;
-    cfg.shade_slab = RT_STATIC_SLAB;
-    KernelTimer kt;  // (off)
-    if (d_primid) HIPOK(hipMemsetAsync(d_primid, 0xFF, (size_t)n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
-    for (size_t t0 = 0; t0 < (size_t)n_local; t0 += chunk_tiles) {
-        const uint32_t ntiles = (uint32_t)std::min<size_t>(chunk_tiles, (size_t)n_local - t0);
-        // the scratch keeps the last call's contents: the counters must start at zero (queue lengths, work cursors);
-        // queues and accumulators are written before they are read (level-0 k_shade stores every sample slot)
-        HIPOK(hipMemsetAsync(q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
-        rtLaunchGenPrimary(cfg, f, q, (uint32_t)t0, ntiles);
-        runLevels(ctx, q, cfg, p->max_depth, p->spp, (uint32_t)t0, (uint32_t *)d_primid, 0, kt, nullptr, (uint64_t)ntiles * per_tile);
-        rtLaunchResolve(cfg, f, q, (uint32_t)t0, ntiles, (uint8_t *)d_rgb8, (float *)d_rgbf);
-    }
-    HIPOK(hipGetLastError());
-    return 0;
+    return renderTilesStatic(ctx, cam, p, (uint8_t *)d_rgb8, (float *)d_rgbf, (uint32_t *)d_primid, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int rt_render(rt_context *ctx, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8, float *out_rgbf,
@@ -1133,58 +601,7 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
     rt_stats local{};
     rt_stats *st = stats ? stats : &local;
     std::memset(st, 0, sizeof *st);
-    // rays per pass: 1 Mi, halved until the worst case of the deepest level (2^depth rays per input ray) fits 32-bit
-    // queue indices and the free memory
-    size_t chunk = std::min<size_t>(std::max<int64_t>(n, 1), (size_t)1 << 20);
-    {
-        size_t free_b = 0, total_b = 0;
-        HIPOK(hipMemGetInfo(&free_b, &total_b));
-        const size_t budget = (free_b + ctx->ws_bytes) / 8 * 7;
-        const int fo = worstFanout(depth), nl = std::max<int>(1, (int)ctx->lights.size());
-        while (chunk > 1) {
-            const QueueSizes z = queueSizes(ctx, chunk, fo, nl);
-            if (z.fits32 && z.bytes <= budget) break;
-            chunk /= 2;
-        }
-    }
-    if (ensureWorkspace(ctx, chunk, depth, (int)ctx->lights.size())) return 1;
-    RtLaunchCfg cfg = ctx->cfg;
-    cfg.stream = ctx->stream;
-    DevBuf<float> d_rays, d_col;
-    DevBuf<rt_hit> d_hits;
-    DevBuf<uint8_t> d_sh;
-    KernelTimer kt;
-    int rc = 0;
-    for (int64_t off = 0; off < n && !rc; off += (int64_t)chunk) {
-        const uint32_t m = (uint32_t)std::min<int64_t>(chunk, n - off);
-        rc = d_rays.alloc((size_t)m * 6) || d_col.alloc((size_t)m * 3) || d_hits.alloc(m) || d_sh.alloc((size_t)m * 4);
-        if (rc) break;
-        hipError_t e = hipMemcpyAsync(d_rays.p, rays + 6 * off, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice, cfg.stream);
-        if (e == hipSuccess) e = hipMemsetAsync(ctx->q.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), cfg.stream);
-        if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
-        rtLaunchRaysFromHost(cfg, d_rays.p, m, ctx->q);
-        // level 0 closest hit first: the hit records of the batch are reported from it
-        rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, 0, 0);
-        if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, ctx->q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
-        runLevels(ctx, ctx->q, cfg, depth, 1, 0, nullptr, 0, kt, st, m, true);
-        rtLaunchBatchColors(cfg, ctx->q, m, d_col.p);
-        std::vector<uint32_t> hc(RT_CNT_WORDS);
-        e = hipStreamSynchronize(cfg.stream);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpy(hc.data(), ctx->q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && out_color) e = hipMemcpy(out_color + 3 * off, d_col.p, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && out_hits) e = hipMemcpy(out_hits + off, d_hits.p, (size_t)m * sizeof(rt_hit), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && out_shadow) e = hipMemcpy(out_shadow + 4 * off, d_sh.p, (size_t)m * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
-        addCounters(st, hc.data(), depth);
-        if (out_hits) {  // slot -> triangle index inside its mesh
-            for (uint32_t k = 0; k < m; k++) {
-                rt_hit &h = out_hits[off + k];
-                if (h.hit && h.triangle >= 0) h.triangle = (int32_t)((int64_t)h.prim - ctx->mesh_first[h.object]);
-            }
-        }
-    }
-    d_rays.release(); d_col.release(); d_hits.release(); d_sh.release();
+    int rc = traceBatch(ctx, n, rays, depth, out_color, out_hits, out_shadow, st);
     st->primary_samples = (uint64_t)n;
     if (!rc && st->queue_overflow) rc = fail("wavefront queue overflow");
     return rc;

@@ -7,34 +7,40 @@ struct RtLaunchCfg {
     hipStream_t stream = nullptr;
     int num_cus = 256;             // from hipDeviceProp_t at rt_create
     int stack_entries = 16;        // LDS traversal stack rows per lane (chosen at rt_commit); deeper entries spill to global memory
-    bool packets = true;           // run the packet kernels first (needs a tree whose worst-case stack fits 64 entries)
-    // levels (from 0) whose closest-hit / shadow queues go through the packet kernels first.  Measured on the
-    // competition scene at 4K/64 spp (profiles/r01_packet_levels.md): only primary rays are coherent enough to pay.
-    int packet_levels_closest = 1;
-    int packet_levels_any = 0;
+    bool packets = true;           // primary rays go through the packet kernel first (needs a tree whose worst-case stack fits 64
+                                   // entries).  Only primary rays are coherent enough to pay (profiles/r01_packet_levels.md)
     int analytic_bytes = 0;        // LDS behind the stack holding the staged spheres + planes
     int split_budget = 1024;       // wave iterations (a power of two) after which a shadow ray's walk is split into work items (0 = never)
     int trace_blocks_per_cu = 4;   // resident 256-thread blocks per CU for the traversal kernels (LDS-limited)
     int shade_blocks = 0;          // k_shade grid in blocks; 0 = num_cus * RT_SHADE_BLOCKS_PER_CU (rt_render_tiles_static
                                    // uses a small grid: every wave owns (lights + 1) output slabs, i.e. queue slack)
-    uint32_t shade_slab = 0;       // slots per slab; 0 = chosen from the level's size (rtLaunchShade)
+    uint32_t shade_slab = 0;       // slots per slab; 0 = chosen from the queue's size (rtShadeSlab)
 };
 
-void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles);
-// stats: 0 plain, 1 counters, 2 + wave-time profile; part: 0 = packet kernel (if the level has one) + per-lane kernels,
-// 1 = packet kernel only, 2 = per-lane kernels only (separate timing)
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part = 0);
-void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part = 0);
-inline bool rtLevelUsesPackets(const RtLaunchCfg &cfg, int level, bool any) {
-    return cfg.packets && level < (any ? cfg.packet_levels_any : cfg.packet_levels_closest);
-}
-void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
+// One ITERATION of the pipeline works on ray queue `par` (0 / 1): entries [0, q.prim_n) are the primary rays of the chunk
+// that enters, behind them the bounce rays (levels 1..D) the previous iteration's k_shade appended.
+void rtLaunchIterCtl(const RtLaunchCfg &cfg, const RtQueues &q, int prev, uint32_t prim_next, bool set_cur, uint32_t prim_cur);
+void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, int par, uint32_t tile0, uint32_t ntiles);
+// stats: 0 plain, 1 counters, 2 + wave-time profile
+void rtLaunchPacket(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stats, bool resid);
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
+void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int par, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs);
 // waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)
 inline int rtShadeBlocks(const RtLaunchCfg &cfg) { return cfg.shade_blocks > 0 ? cfg.shade_blocks : cfg.num_cus * RT_SHADE_BLOCKS_PER_CU; }
 inline int rtShadeWaves(const RtLaunchCfg &cfg) { return rtShadeBlocks(cfg) * (RT_BLOCK / 64); }
-void rtLaunchFold0(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t samples, int nlights);
-void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
+// slots per slab for a queue of up to `max_inputs` entries: at most an eighth of what a wave can receive, so that the
+// unused tails stay a small part of the queues
+inline uint32_t rtShadeSlab(const RtLaunchCfg &cfg, uint64_t max_inputs) {
+    if (cfg.shade_slab) return cfg.shade_slab;
+    const uint64_t waves = (uint64_t)rtShadeWaves(cfg);
+    uint32_t slab = 64;
+    while (slab < RT_SLAB_MAX && (uint64_t)slab * 16 * waves <= max_inputs) slab <<= 1;
+    return slab;
+}
+void rtLaunchFold0(const RtLaunchCfg &cfg, const RtQueues &q, int nlights);
+void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t sample0, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles);
 void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,
                       const void *tf, const void *tp, void *o8, void *of, void *op);

@@ -386,9 +386,10 @@ RT_DEV uint32_t compact1By1(uint32_t x) {
     return x;
 }
 
-// Level 0 needs no compaction: slot == sample index inside the chunk.  Slots of pixels outside the image (ragged
-// edge tiles) are flagged invalid; k_closest records a miss for them and k_shade ignores them.
-__global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues q, uint32_t tile0, uint32_t ntiles) {
+// Level 0 needs no compaction: slot == sample index inside the chunk; the slots [0, total) of the iteration's ray queue
+// are reserved for them (k_iter_ctl starts the queue's counter at `total`, k_shade appends behind).  Slots of pixels
+// outside the image (ragged edge tiles) are flagged invalid; k_closest records a miss for them and k_shade ignores them.
+__global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues q, int par, uint32_t tile0, uint32_t ntiles) {
     const uint32_t total = ntiles * RT_TILE_PIXELS * (uint32_t)f.spp;
     uint32_t invalid = 0;
     for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * RT_BLOCK) {
@@ -397,7 +398,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
         const uint32_t gt = lt * (uint32_t)f.tile_world + (uint32_t)f.tile_rank;
         const int i = (int)((gt % (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m));
         const int j = (int)((gt / (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m >> 1));
-        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 1, __uint_as_float(idx | RT_FLAG_INVALID));
+        const uint32_t tag = q.prim_sample0 + idx;  // ring sample, level 0
+        float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 1, __uint_as_float(tag | RT_FLAG_INVALID));
         if (i < f.width && j < f.height) {
             float jx, jy;
             if (f.use_table) {  // jitterMatrix, main.cpp:601-606 (selects, not an indexed array: no scratch)
@@ -411,15 +413,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
             const float dy = f.Y - ((float)j + jy) * f.s - f.s / 2;
             const V3 d = normalize(mulPoint(f.rot, v3(dx, dy, f.dz), 0.0f));  // :637-641
             A = make_float4(f.origin[0], f.origin[1], f.origin[2], 1.0f);
-            B = make_float4(d.x, d.y, d.z, __uint_as_float(idx));
+            B = make_float4(d.x, d.y, d.z, __uint_as_float(tag));
         } else {
             invalid++;
         }
-        q.rayA[0][idx] = A;
-        q.rayB[0][idx] = B;
-        q.rayR[0][idx] = 1.0f;
+        q.rayA[par][idx] = A;
+        q.rayB[par][idx] = B;
+        q.rayR[par][idx] = 1.0f;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) q.counters[RT_CNT_RAYS(0)] = min(total, q.ray_cap);
     if (__ballot(invalid != 0)) {
         for (int off = 32; off > 0; off >>= 1) invalid += __shfl_down(invalid, off);
         if (laneId() == 0 && invalid) atomicAdd(q.counters + RT_CNT_INVALID, invalid);
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 // index; direction, light distance and the epsilon-offset origin are recomputed with the expressions k_shade uses
 // (same operations, same order => same bits), which keeps the record at 32 bytes instead of 48.
 RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, uint32_t light, RtRay &r, float &dist, uint32_t &sample) {
-    sample = __float_as_uint(A.w) & RT_SAMPLE_MASK;
+    sample = __float_as_uint(A.w);  // ring sample | RT_SHADOW_L0
     const V3 P = v3(A.x, A.y, A.z), lp = ld3(sc.lights[light].pos);
     const V3 ld = normalize(lp - P);  // main.cpp:97
     dist = length(lp - P);            // :98
@@ -468,40 +469,42 @@ RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, uint32_t light, RtRay &r
 // (MODE 2) walk the items with all lanes, exporting again what is still long; the last one has no budget.  The ray's
 // join word (shC.w as u32) counts its outstanding items; an item that finds a hit sets RT_JOIN_OCCLUDED; the item
 // that brings the count to zero adds the pending radiance if the flag is clear.  Same sums, same bits as unsplit.
-#define RT_MODE_QUEUE 0   // the level's queue
-#define RT_MODE_RESID 1   // the rays the packet kernel handed over (q.resid holds their queue indices)
-#define RT_MODE_SPLIT 2   // work items of split any-hit walks (round `round` of the level)
+#define RT_MODE_QUEUE 0   // the iteration's queue (closest-hit: entries [first, n) -- the packet kernel takes the primary rays before)
+#define RT_MODE_RESID 1   // the primary rays the packet kernel handed over (q.resid holds their queue indices)
+#define RT_MODE_SPLIT 2   // work items of split any-hit walks (round `round` of the iteration)
 
 // L0: level-0 shadow results are stored, not added (RtQueues::occ0) -- an instance of its own, so that the usual one keeps
 // its registers
 template <bool ANY, int STATS, int MODE, bool L0 = false>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
-RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stack_entries, int round,
+RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stack_entries, int round,
                        uint32_t budget) {
-    if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(level, round)] == 0) return;  // the usual case: nothing was split
+    if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(par, round)] == 0) return;  // the usual case: nothing was split
     constexpr bool COUNT = STATS >= 1, PROF = STATS >= 2;
     extern __shared__ uint32_t s_lds[];
     const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
     // one LDS row behind the stack: the wave iteration at which the lane took its ray
     RtLdsWord *const age = (RtLdsWord *)(s_lds + stack_entries * RT_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
     const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);
-    const int buf = level & 1;
+    const int buf = par;
     constexpr bool INDIRECT = MODE == RT_MODE_RESID, SPLIT = MODE == RT_MODE_SPLIT;
     constexpr uint32_t batch = ANY ? RT_FETCH_BATCH_ANY : RT_FETCH_BATCH_CLOSEST;
     static_assert(ANY || !SPLIT, "only any-hit walks are split");
-    const uint32_t n = SPLIT ? min(q.counters[RT_CNT_SPLIT(level, round)], q.split_cap)
-                     : INDIRECT ? q.counters[ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)]
-                                : (ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap));
-    uint32_t *work = q.counters + (SPLIT ? RT_CNT_SPLIT(level, round) + 1 : ANY ? RT_CNT_WORK_ANY(level) : RT_CNT_WORK_CLOSEST(level));
-    // The level's queue is cut into RT_WORK_PARTS contiguous parts with a cursor each (on its own 128-byte line): one
+    static_assert(!ANY || !INDIRECT, "only primary rays go through the packet kernel");
+    const uint32_t n = SPLIT ? min(q.counters[RT_CNT_SPLIT(par, round)], q.split_cap)
+                     : INDIRECT ? q.counters[RT_CNT_RESID(par)]
+                                : (ANY ? min(q.counters[RT_CNT_SHADOW(par)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap));
+    uint32_t *work = q.counters + (SPLIT ? RT_CNT_SPLIT(par, round) + 1 : RT_CNT_WORK_RESID(par));
+    // The queue is cut into RT_WORK_PARTS contiguous parts with a cursor each (on its own 128-byte line): one
     // cursor for the whole chip saturates -- a returning atomic on one address retires every ~10 ns.  A wave starts
     // in the part of its XCD (workgroups go round-robin over the 8 XCDs) and moves on when a part is used up.
     constexpr uint32_t PARTS = MODE == RT_MODE_QUEUE ? RT_WORK_PARTS : 1u;
-    uint32_t *work_parts = q.counters + (ANY ? RT_CNT_WORKP_ANY(level, 0) : RT_CNT_WORKP_CLOSEST(level, 0));
-    const uint32_t part_len = PARTS > 1 ? ((n + PARTS - 1) / PARTS + batch - 1) / batch * batch : n;
+    uint32_t *work_parts = q.counters + (ANY ? RT_CNT_WORKP_ANY(par, 0) : RT_CNT_WORKP_CLOSEST(par, 0));
+    const uint32_t span = n > first ? n - first : 0u;     // entries [first, n) are this launch's
+    const uint32_t part_len = PARTS > 1 ? ((span + PARTS - 1) / PARTS + batch - 1) / batch * batch : span;
     uint32_t part = PARTS > 1 ? blockIdx.x % PARTS : 0u, parts_done = 0;  // wave-uniform
     const uint2 *items_in = q.split[round & 1];
     uint2 *items_out = q.split[(round + 1) & 1];          // the queue pass is round -1
-    uint32_t *items_out_count = q.counters + RT_CNT_SPLIT(level, round + 1);
+    uint32_t *items_out_count = q.counters + RT_CNT_SPLIT(par, round + 1);
     uint32_t iter = 0;                                     // wave iterations of the walk loop so far (uniform)
     // the wave passes the top of its outer loop (where long lanes are looked for) at least every period + 1 iterations
     const uint32_t period = (budget && budget < 1024u) ? budget - 1u : 1023u;  // budget is a power of two
@@ -555,12 +558,12 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             occl = false;
         }
         if (COUNT && ANY && add) unocc++;
-        if (ANY && add && l0store) {
-            const size_t at = (size_t)lightw * q.l0_stride + smp;
+        if (ANY && add && l0store && (smp & RT_SHADOW_L0)) {  // (level-0 hits of this iteration: ring samples from prim_sample0)
+            const size_t at = (size_t)lightw * q.l0_stride + ((smp & q.sample_mask) - q.prim_sample0);
             q.col0[at] = C;
             q.occ0[at] = 1;
         } else if (ANY && add) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * smp;
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * (smp & q.sample_mask);
             atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
             atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
             atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
@@ -613,7 +616,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
         const unsigned long long idle2 = __ballot(!has);
         if (idle2 && more) {
             while (pool_next >= pool_end && parts_done < PARTS) {
-                const uint32_t lo = part * part_len, hi = min(lo + part_len, n);
+                const uint32_t lo = first + part * part_len, hi = min(lo + part_len, n);
                 // (two batch sizes: one generation of rays once the part is nearly used up -- as far as this wave knows from
                 // its previous fetch -- so that a launch does not end with a few waves walking 256 rays each)
                 const uint32_t want = lo + part_seen + tail_len >= hi ? 64u : batch;
@@ -663,7 +666,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     // even entries first, then the odd ones (order is free: results go to the ray's own slot): 39 -> 42 of
                     // 64 lanes per node phase, k_closest 179 -> 161 ms on the 4K frame.  (Unpaired rays shift the parity;
                     // that only weakens the separation.)
-                    if (!ANY && !INDIRECT && level > 0) {
+                    if (!ANY && !INDIRECT) {
                         const uint32_t off = pos - pool_base, len = pool_end - pool_base, half = (len + 1u) >> 1;
                         pos = pool_base + (off < half ? 2u * off : 2u * (off - half) + 1u);
                     }
@@ -832,44 +835,30 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
 typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) u16v *RtScalarRecs;  // constant address space: uniform loads become s_load
 
-template <bool ANY, bool STATS>
-RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtQueues &q, int level,
+template <bool STATS>
+RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtQueues &q, int par,
                         uint32_t pb, uint32_t n, unsigned long long *prof) {
     const uint32_t lane = laneId();
-    const int buf = level & 1;
+    const int buf = par;
     const uint32_t i = pb + lane;
     const bool valid = i < n;
     RtWalk w;
     float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f), B = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
     if (valid) {
-        A = ANY ? q.shA[i] : q.rayA[buf][i];
-        if (!ANY) B = q.rayB[buf][i];
+        A = q.rayA[buf][i];
+        B = q.rayB[buf][i];
     }
-    const bool hole = ANY && __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
-    uint32_t sample = __float_as_uint(B.w);
-    float ldist = 0.0f;
-    if (ANY) {
-        rtShadowRay(sc, A, (valid && !hole) ? (uint32_t)q.shL[i] : 0u, w.r, ldist, sample);  // (a hole's light byte was never written)
-    } else {
-        w.r.o = v3(A.x, A.y, A.z);
-        w.r.d = v3(B.x, B.y, B.z);
-    }
+    const uint32_t sample = __float_as_uint(B.w);
+    w.r.o = v3(A.x, A.y, A.z);
+    w.r.d = v3(B.x, B.y, B.z);
     rtInitWalk(sc, w, root_ref);
-    bool alive = valid && !hole;
-    if (ANY) {
-        w.best_t = ldist;  // light distance
-        w.best_id = RT_ID_MISS;
-        w.best_obj = 0;
-        w.best_rank = 0;
-        if (alive && analyticOccluded(sc, an, w, ldist)) alive = false;
-    } else {
-        w.best_t = INFINITY;
-        w.best_id = RT_ID_MISS;
-        w.best_obj = 0x7FFFFFFF;
-        w.best_rank = 0;
-        if (sample & RT_FLAG_INVALID) alive = false;  // slot of a pixel outside the image: recorded as a miss
-        if (alive) analyticClosest(sc, an, w);
-    }
+    bool alive = valid;
+    w.best_t = INFINITY;
+    w.best_id = RT_ID_MISS;
+    w.best_obj = 0x7FFFFFFF;
+    w.best_rank = 0;
+    if (sample & RT_FLAG_INVALID) alive = false;  // slot of a pixel outside the image: recorded as a miss
+    if (alive) analyticClosest(sc, an, w);
     const unsigned long long am = __ballot(alive);
     bool toResid = false;
     // error bound of a plane distance folded into o/d: near planes move towards the origin, far planes away
@@ -878,17 +867,16 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
     const RtScalarRecs nodesP = (RtScalarRecs)(const void *)sc.nodes_p;
     const RtScalarRecs recs = (RtScalarRecs)(const void *)sc.nodes;
     int steps = 0;
-    // One walk per direction octant present in the packet (usually one; two where a packet straddles two lights or
-    // mixes reflection and refraction rays): inside a group near / far planes are chosen once, on the scalar unit.
+    // One walk per direction octant present in the packet (usually one): inside a group near / far planes are chosen
+    // once, on the scalar unit.
     for (unsigned long long rem = sc.n_tris ? am : 0ull; rem && !toResid;) {
         const uint32_t oct = __builtin_amdgcn_readlane(octant, (int)__builtin_ctzll(rem));
-        const bool inGroup = alive && octant == oct;  // alive: shadow rays already found occluded stay out
+        const bool act = alive && octant == oct;
         rem &= ~__ballot(octant == oct);
         if (STATS) prof[6]++;
         const bool negx = oct & 1u, negy = oct & 2u, negz = oct & 4u;
         uint32_t cur = __builtin_amdgcn_readfirstlane(root_ref), vstack = 0;
         int sp = 0;
-        bool act = inGroup;
         while (cur != RT_NODE_DONE) {
             if (!(cur & RT_NODE_LEAF)) {
                 if (++steps > RT_PACKET_BUDGET) {
@@ -924,7 +912,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
                 for (int c = 0; c < 4; c++) {
                     ref[c] = n1[8 + c];
                     key[c] = 0xFFFFFFFFu;
-                    if (m[c]) key[c] = ANY ? (uint32_t)c : __builtin_amdgcn_readlane(__float_as_uint(tnv[c]), (int)__builtin_ctzll(m[c]));
+                    if (m[c]) key[c] = __builtin_amdgcn_readlane(__float_as_uint(tnv[c]), (int)__builtin_ctzll(m[c]));
                 }
 #define RT_CSWAP(a, b)                                                  \
     if (key[b] < key[a]) {                                              \
@@ -959,57 +947,41 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
                     T.n = v3(__uint_as_float(tr[3]), __uint_as_float(tr[7]), __uint_as_float(tr[11]));
                     float t = 0.0f;
                     const bool hit = act && rtTriHit(T, w.r, w.best_t, t);
-                    if (ANY) {
-                        if (hit) {
-                            alive = false;  // occluded: the pending radiance is dropped
-                            act = false;
-                        }
-                    } else {  // (selects after the test, as in rtTriStep)
-                        const int obj = (int)tr[12];
-                        const uint32_t rank = tr[13];
-                        const bool take = hit && (t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
-                                                                   (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank))));
-                        w.best_t = take ? t : w.best_t;
-                        w.best_id = take ? ((first + k - (uint32_t)sc.n_nodes) | tr[15]) : w.best_id;  // (| RT_ID_GENERAL flag)
-                        w.best_obj = take ? obj : w.best_obj;
-                        w.best_rank = take ? rank : w.best_rank;
-                    }
+                    // (selects after the test, as in rtTriStep)
+                    const int obj = (int)tr[12];
+                    const uint32_t rank = tr[13];
+                    const bool take = hit && (t < w.best_t || (t == w.best_t && w.best_id != RT_ID_MISS &&
+                                                               (obj < w.best_obj || (obj == w.best_obj && rank < w.best_rank))));
+                    w.best_t = take ? t : w.best_t;
+                    w.best_id = take ? ((first + k - (uint32_t)sc.n_nodes) | tr[15]) : w.best_id;  // (| RT_ID_GENERAL flag)
+                    w.best_obj = take ? obj : w.best_obj;
+                    w.best_rank = take ? rank : w.best_rank;
                 }
-                if (ANY && !__ballot(act)) break;  // every ray of the group is occluded
                 cur = sp ? __builtin_amdgcn_readlane(vstack, --sp) : RT_NODE_DONE;
             }
         }
     }
     if (toResid) {  // hand the packet's live rays to the per-lane kernel (which starts them from scratch)
-        const bool go = ANY ? alive : (valid && !(sample & RT_FLAG_INVALID));  // shadow rays found occluded meanwhile are done
+        const bool go = valid && !(sample & RT_FLAG_INVALID);
         const unsigned long long gm = __ballot(go);
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(q.counters + (ANY ? RT_CNT_RESID_ANY(level) : RT_CNT_RESID_CLOSEST(level)), (uint32_t)__popcll(gm));
+        if (lane == 0) base = atomicAdd(q.counters + RT_CNT_RESID(par), (uint32_t)__popcll(gm));
         base = __builtin_amdgcn_readfirstlane(base);
         if (go) q.resid[base + maskRankBelow(gm)] = i;
         if (STATS) prof[7] += (unsigned long long)__popcll(gm);
-        if (!ANY && valid && !go) q.hits[i] = make_float2(INFINITY, __uint_as_float(RT_ID_MISS));
+        if (valid && !go) q.hits[i] = make_float2(INFINITY, __uint_as_float(RT_ID_MISS));
         return;
     }
-    if (ANY) {
-        if (alive) {  // unoccluded: the pending radiance of the light arrives
-            const float4 C = q.shC[i];
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * sample;
-            atomicAdd(acc + 0, (unsigned long long)rtToFixed(C.x));
-            atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
-            atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
-        }
-    } else if (valid) {
-        q.hits[i] = make_float2(w.best_t, __uint_as_float(w.best_id));
-    }
+    if (valid) q.hits[i] = make_float2(w.best_t, __uint_as_float(w.best_id));
 }
 
-template <bool ANY, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level) {
+// the primary rays of the iteration: entries [0, q.prim_n) of ray queue `par`
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par) {
     extern __shared__ uint32_t s_lds[];
     const RtAnalytic an = stageAnalytic(sc, s_lds);
-    const uint32_t n = ANY ? min(q.counters[RT_CNT_SHADOW(level)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
-    uint32_t *work = q.counters + (ANY ? RT_CNT_PWORK_ANY(level) : RT_CNT_PWORK_CLOSEST(level));
+    const uint32_t n = min(q.prim_n, q.ray_cap);
+    uint32_t *work = q.counters + RT_CNT_PWORK(par);
     // STATS: [0] packets, [1] node steps, [2] lanes interested in a child per node step, [3] triangle steps, [4] live
     // lanes per triangle step, [5] packets over budget, [6] octant groups walked, [7] rays handed to the lane kernel
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1029,28 +1001,28 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t 
         const uint32_t end = min(base + want, n);
         for (uint32_t pb = base; pb < end; pb += 64u) {
             if (STATS) prof[0]++;
-            tracePacket<ANY, STATS>(sc, an, root_ref, q, level, pb, n, prof);
+            tracePacket<STATS>(sc, an, root_ref, q, par, pb, n, prof);
         }
     }
     if (STATS && laneId() == 0) {
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + (ANY ? RT_CNT_PROF_PACKET_ANY : RT_CNT_PROF_PACKET_CLOSEST));
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + RT_CNT_PROF_PACKET);
         for (int k = 0; k < 8; k++) atomicAdd(dst + k, prof[k]);
     }
 }
 
 template <int STATS, int MODE>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries) {
-    traceQueue<false, STATS, MODE>(sc, root_ref, q, level, stack_entries, -1, 0u);
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, uint32_t first, int stack_entries) {
+    traceQueue<false, STATS, MODE>(sc, root_ref, q, par, first, stack_entries, -1, 0u);
 }
 template <int STATS, int MODE, bool L0 = false>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int level, int stack_entries, int round,
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries, int round,
                                                      uint32_t budget) {
-    traceQueue<true, STATS, MODE, L0>(sc, root_ref, q, level, stack_entries, round, budget);
+    traceQueue<true, STATS, MODE, L0>(sc, root_ref, q, par, 0u, stack_entries, round, budget);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PhongModel without its nested closest()/is_shadowed() calls (main.cpp:81-213).  One lane per traced ray of
-// `level`; remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
+// PhongModel without its nested closest()/is_shadowed() calls (main.cpp:81-213).  One lane per traced ray of the
+// iteration's queue (rays of every level, the level rides in the ray's tag); remaining bounce budget = max_depth - level.  A node's colour is linear in its children except for the
 // Fresnel coupling (main.cpp:187-203), which is resolved here from the sibling's hit record.
 // Colour-only math of PhongModel (its results feed radiance, never a ray): the reference's libm calls are not bit-exact
 // on the device anyway (BASELINE tolerance: 8-bit RGB within 1, PSNR >= 50 dB), so these use the hardware's
@@ -1084,7 +1056,7 @@ RT_DEV float colorPowMax0(float x, float y) {
 // cannot shade (RT_ID_GENERAL in the id, or a sphere / cone) go to a list (q.general) that the GENERAL instance -- the
 // full body -- works off afterwards; it is launched only for scenes that hold such primitives.
 template <bool PROF, bool GENERAL>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSceneDev sc, RtQueues q, int level, int max_depth, int spp,
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSceneDev sc, RtQueues q, int par, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles, uint32_t slab) {
     constexpr bool FAST = !GENERAL;
     // Output slots come from WAVE-PRIVATE slabs: a wave reserves `slab` consecutive slots of the shadow queue per light
@@ -1096,17 +1068,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     uint32_t curv = 0, endv = 0, holesS = 0, holesR = 0;
     uint32_t gcur = 0, gend = 0;  // the wave's slab of the general list (wave-uniform)
     const uint32_t slabS = slab, slabR = max(slab, 128u);  // one iteration emits at most 64 shadow rays per light, 128 rays
-    const int buf = level & 1, nbuf = buf ^ 1;
-    const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(level)], q.ray_cap) : min(q.counters[RT_CNT_RAYS(level)], q.ray_cap);
+    const int buf = par, nbuf = par ^ 1;
+    const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(par)], q.ray_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap);
     // A wave shades SEGMENTS of consecutive queue entries (consecutive entries are neighbouring samples / hits), so the
     // rays it appends to a slab leave neighbouring points towards one light.  Segments are dealt round-robin to the
     // waves; their length adapts to the queue so that every wave still gets several.
     const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64), gwave = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6);
     const uint32_t seg = min(max((n / (nwaves * 8u)) & ~63u, 64u), RT_SHADE_SEGMENT);
-    const int remaining = max_depth - level;
     const uint32_t lane = laneId();
     const int nlights = sc.n_lights;
-    uint32_t culled = 0, shaded = 0, zero = 0;
+    uint32_t culled = 0, shaded = 0, zero = 0, l0lit = 0;
     // PROF build: shader clocks per section, summed over waves: [0] loads + hit reconstruction, [1] material, light
     // culling, textures, ambient, bounce set-up, [2] the scan for hits, [3] direct light + shadow-ray emission,
     // [4] next-level emission, [5] iterations
@@ -1129,8 +1100,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             const uint32_t qi = GENERAL ? (valid ? q.general[j] : RT_GENERAL_HOLE) : j;
             const uint32_t hid = GENERAL ? 0u : __float_as_uint(q.hits[valid ? j : 0].y);
             bool hit = valid && (GENERAL ? qi != RT_GENERAL_HOLE : hid != RT_ID_MISS);
-            if (!GENERAL && level == 0 && valid && !hit) {  // miss, or slot outside the image: the sample's first and only level-0 entry
-                long long *acc = q.accum + 3ull * (__float_as_uint(q.rayB[buf][j].w) & RT_SAMPLE_MASK);
+            if (!GENERAL && j < q.prim_n && valid && !hit) {  // primary ray that missed, or slot outside the image: the sample's first and only level-0 entry
+                long long *acc = q.accum + 3ull * (q.prim_sample0 + j);
                 acc[0] = 0;
                 acc[1] = 0;
                 acc[2] = 0;
@@ -1143,7 +1114,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                     const uint32_t c = (uint32_t)__popcll(gm), rank = maskRankBelow(gm), room = gend - gcur;
                     uint32_t slot = gcur + rank;
                     if (c > room) {  // the slab is used up to its last slot, the rest opens the next one
-                        const uint32_t nbase = waveReserve(q.counters + RT_CNT_GENERAL(level), slabR);
+                        const uint32_t nbase = waveReserve(q.counters + RT_CNT_GENERAL(par), slabR);
                         if (rank >= room) slot = nbase + (rank - room);
                         gcur = nbase + (c - room);
                         gend = nbase + slabR;
@@ -1185,10 +1156,12 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             B = q.rayB[buf][i];
         }
         const uint32_t id = __float_as_uint(hrec.y);
-        const uint32_t sflags = __float_as_uint(B.w), sample = sflags & RT_SAMPLE_MASK;
-        if (active && level == 0 && primid_tiles && (sample % (uint32_t)spp) == 0) {
+        const uint32_t sflags = __float_as_uint(B.w), sample = sflags & q.sample_mask;
+        const uint32_t level = (sflags >> q.level_shift) & q.level_mask;   // per ray: the queue mixes the levels of D + 1 chunks
+        const int remaining = max_depth - (int)level;
+        if (active && level == 0 && primid_tiles && ((sample - q.prim_sample0) % (uint32_t)spp) == 0) {
             // primitive hit by sample 0 of the pixel, written tile-major at y*16+x (misses keep the buffer's RT_PRIM_MISS)
-            const uint32_t pm = sample / (uint32_t)spp, m = pm & 255u;
+            const uint32_t pm = (sample - q.prim_sample0) / (uint32_t)spp, m = pm & 255u;
             const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
             const uint32_t kind = id & RT_ID_KIND_MASK;
             uint32_t prim;
@@ -1278,7 +1251,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         }
 
         // ambient term of the hit (levels >= 1); an exactly zero term (materials without ambient colour) adds nothing
-        if (level > 0) accumulateRuns(q.accum, active && !(amb0.x == 0.0f && amb0.y == 0.0f && amb0.z == 0.0f), sample, amb0);
+        accumulateRuns(q.accum, active && level > 0 && !(amb0.x == 0.0f && amb0.y == 0.0f && amb0.z == 0.0f), sample, amb0);
         if (level == 0 && active) {
             // Level 0 holds exactly one entry per sample slot (hit, miss or outside the image), and it is the first to
             // touch the slot: a plain store initialises the accumulator -- no memset of the buffer, no atomics here.
@@ -1343,7 +1316,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             const uint32_t room = end - cur;
             uint32_t slot = cur + rank;
             if (c > room) {  // the slab is used up to its last slot, the rest of the rays opens the next one
-                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(level), slabS);
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(par), slabS);
                 if (rank >= room) slot = nbase + (rank - room);
                 cur = nbase + (c - room);
                 end = nbase + slabS;
@@ -1356,7 +1329,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             }
             if (lit) {
                 if (slot < q.shadow_cap) {  // 33-byte record: point + sample, light, pending colour (rtShadowRay rebuilds the ray)
-                    q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample));
+                    q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | (level == 0 ? RT_SHADOW_L0 : 0u)));
+                    if (level == 0) l0lit++;
                     q.shL[slot] = (uint8_t)l;
                     q.shC[slot] = make_float4(c3.x, c3.y, c3.z, 0.0f);
                 } else {
@@ -1375,7 +1349,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             const uint32_t room = end - cur;
             uint32_t slot = cur + off;
             if (c > room) {
-                const uint32_t nbase = waveReserve(q.counters + RT_CNT_RAYS(level + 1), slabR);
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_RAYS(nbuf), slabR);
                 // first lane whose rays do not fit any more: it and the lanes after it move to the new slab
                 const unsigned long long nofit = __ballot(k > 0 && off + k > room);
                 const uint32_t f = (uint32_t)__ffsll((long long)nofit) - 1u;
@@ -1394,12 +1368,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 curv = cur;
                 endv = end;
             }
+            const uint32_t ntag = sample | ((level + 1u) << q.level_shift);  // the children are one level deeper
             if (emitRefl) {
                 if (slot < q.ray_cap) {
                     const V3 ro = P + RT_EPSILON * reflDir;  // main.cpp:155
                     q.rayA[nbuf][slot] = make_float4(ro.x, ro.y, ro.z, wRefl);
                     q.rayB[nbuf][slot] = make_float4(reflDir.x, reflDir.y, reflDir.z,
-                                                     __uint_as_float(sample | (emitRefr ? RT_FLAG_HAS_REFR_SIBLING : 0u)));
+                                                     __uint_as_float(ntag | (emitRefr ? RT_FLAG_HAS_REFR_SIBLING : 0u)));
                     q.rayR[nbuf][slot] = fresnelR;
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
@@ -1410,7 +1385,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 if (slot < q.ray_cap) {
                     const V3 ro = P + RT_EPSILON * refrDir;  // main.cpp:181
                     q.rayA[nbuf][slot] = make_float4(ro.x, ro.y, ro.z, wRefr);
-                    q.rayB[nbuf][slot] = make_float4(refrDir.x, refrDir.y, refrDir.z, __uint_as_float(sample));
+                    q.rayB[nbuf][slot] = make_float4(refrDir.x, refrDir.y, refrDir.z, __uint_as_float(ntag));
                     q.rayR[nbuf][slot] = 1.0f;
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
@@ -1442,6 +1417,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     for (int off = 32; off > 0; off >>= 1) {
         culled += __shfl_down(culled, off);
         zero += __shfl_down(zero, off);
+        l0lit += __shfl_down(l0lit, off);
         shaded += __shfl_down(shaded, off);
         holesS += __shfl_down(holesS, off);
         holesR += __shfl_down(holesR, off);
@@ -1449,16 +1425,19 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     if (lane == 0) {
         if (culled) atomicAdd(q.counters + RT_CNT_CULLED, culled);
         if (zero) atomicAdd(q.counters + RT_CNT_ZERO, zero);
+        if (l0lit) atomicAdd(q.counters + RT_CNT_SHADOW_L0, l0lit);
         if (shaded) atomicAdd(q.counters + RT_CNT_SHADED, shaded);
         if (holesS) atomicAdd(q.counters + RT_CNT_SHADOW_HOLES, holesS);
         if (holesR) atomicAdd(q.counters + RT_CNT_INVALID, holesR);  // ray-queue holes are invalid slots like those of k_gen_primary
     }
 }
 
-// Level-0 shadow results that k_any stored instead of adding (RtQueues::occ0): one lane per sample adds the radiance of
-// its unoccluded level-0 shadow rays to the sample's accumulator.  Runs behind k_any(0) and its split rounds, before
-// anything of level 1 touches the accumulators; no other kernel is active, so plain read-modify-write.
-__global__ __launch_bounds__(RT_BLOCK) void k_fold0(RtQueues q, uint32_t samples, int nlights) {
+// Level-0 shadow results that k_any stored instead of adding (RtQueues::occ0): one lane per sample of the chunk that entered
+// the pipeline in this iteration adds the radiance of its unoccluded level-0 shadow rays to the sample's accumulator and
+// clears the flags for the next iteration.  Runs behind the iteration's k_any and its split rounds, before anything of the
+// chunk's level 1 touches the accumulators; no other kernel is active, so plain read-modify-write.
+__global__ __launch_bounds__(RT_BLOCK) void k_fold0(RtQueues q, int nlights) {
+    const uint32_t samples = q.prim_n;
     for (uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x; s < samples; s += gridDim.x * RT_BLOCK) {
         unsigned long long ax = 0, ay = 0, az = 0;
         bool any = false;
@@ -1470,10 +1449,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold0(RtQueues q, uint32_t samples
                 ay += (unsigned long long)rtToFixed(C.y);
                 az += (unsigned long long)rtToFixed(C.z);
                 any = true;
+                q.occ0[at] = 0;
             }
         }
         if (any) {
-            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * s;
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(q.accum) + 3ull * (q.prim_sample0 + s);
             acc[0] += ax;
             acc[1] += ay;
             acc[2] += az;
@@ -1481,10 +1461,50 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold0(RtQueues q, uint32_t samples
     }
 }
 
+// Between two iterations of the pipeline (one thread; runs at the START of iteration j, before anything else of it):
+// moves the 32-bit counters of iteration j - 1 (parity `prev`) into the frame's 64-bit totals and prepares the counters of
+// that parity for iteration j + 1 -- its ray queue starts behind the `prim_next` slots of the primary rays that will enter
+// then.  No host round trip, no memset between iterations.
+__global__ void k_iter_ctl(RtQueues q, int prev, uint32_t prim_next, int set_cur, uint32_t prim_cur) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t *c = q.counters;
+    unsigned long long *tot = reinterpret_cast<unsigned long long *>(c + RT_CNT_TOTALS);
+    const uint32_t rays = c[RT_CNT_RAYS(prev)], sh = c[RT_CNT_SHADOW(prev)];
+    tot[RT_TOT_RAYS] += rays;
+    tot[RT_TOT_SHADOW] += sh;
+    if (rays > tot[RT_TOT_MAX_RAYS]) tot[RT_TOT_MAX_RAYS] = rays;
+    if (sh > tot[RT_TOT_MAX_SHADOW]) tot[RT_TOT_MAX_SHADOW] = sh;
+    tot[RT_TOT_CULLED] += c[RT_CNT_CULLED];
+    tot[RT_TOT_SHADED] += c[RT_CNT_SHADED];
+    tot[RT_TOT_OVERFLOW] += c[RT_CNT_OVERFLOW];
+    tot[RT_TOT_INVALID] += c[RT_CNT_INVALID];
+    tot[RT_TOT_SHADOW_HOLES] += c[RT_CNT_SHADOW_HOLES];
+    tot[RT_TOT_ZERO] += c[RT_CNT_ZERO];
+    tot[RT_TOT_SHADOW_L0] += c[RT_CNT_SHADOW_L0];
+    c[RT_CNT_CULLED] = c[RT_CNT_SHADED] = c[RT_CNT_OVERFLOW] = c[RT_CNT_INVALID] = 0;
+    c[RT_CNT_SHADOW_HOLES] = c[RT_CNT_ZERO] = c[RT_CNT_SHADOW_L0] = 0;
+    for (int r = 0; r <= RT_SPLIT_ROUNDS; r++) {
+        tot[RT_TOT_SPLIT] += min(c[RT_CNT_SPLIT(prev, r)], q.split_cap);
+        c[RT_CNT_SPLIT(prev, r)] = 0;
+        c[RT_CNT_SPLIT(prev, r) + 1] = 0;
+    }
+    c[RT_CNT_RAYS(prev)] = prim_next;
+    c[RT_CNT_SHADOW(prev)] = 0;
+    c[RT_CNT_GENERAL(prev)] = 0;
+    c[RT_CNT_RESID(prev)] = 0;
+    c[RT_CNT_PWORK(prev)] = 0;
+    c[RT_CNT_WORK_RESID(prev)] = 0;
+    for (int k = 0; k < RT_WORK_PARTS; k++) {
+        c[RT_CNT_WORKP_CLOSEST(prev, k)] = 0;
+        c[RT_CNT_WORKP_ANY(prev, k)] = 0;
+    }
+    if (set_cur) c[RT_CNT_RAYS(prev ^ 1)] = prim_cur;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // trace_ray's clamp per SAMPLE (main.cpp:232), mean over samples (:646), toneMapping (:240-256),
-// Image::setPixel truncation (Image.h:91-95).  One lane per pixel slot of the chunk; outputs are tile-major.
-__global__ __launch_bounds__(RT_BLOCK) void k_resolve(RtFrameDev f, RtQueues q, uint32_t tile0, uint32_t ntiles,
+// Image::setPixel truncation (Image.h:91-95).  One lane per pixel slot of the chunk that leaves the pipeline; outputs are tile-major.
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(RtFrameDev f, RtQueues q, uint32_t sample0, uint32_t tile0, uint32_t ntiles,
                                                      uint8_t *rgb8_tiles, float *rgbf_tiles) {
     const uint32_t total = ntiles * RT_TILE_PIXELS;
     for (uint32_t pm = blockIdx.x * RT_BLOCK + threadIdx.x; pm < total; pm += gridDim.x * RT_BLOCK) {
@@ -1492,7 +1512,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(RtFrameDev f, RtQueues q, 
         const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
         V3 sum = v3s(0.0f);
         for (int s = 0; s < f.spp; s++) {
-            const long long *a = q.accum + 3ull * ((size_t)pm * f.spp + s);
+            const long long *a = q.accum + 3ull * ((size_t)sample0 + (size_t)pm * f.spp + s);  // sample0: the chunk's slot in the accumulator ring
             sum.x += gclamp(rtFromFixed(a[0]), 0.0f, 1.0f);
             sum.y += gclamp(rtFromFixed(a[1]), 0.0f, 1.0f);
             sum.z += gclamp(rtFromFixed(a[2]), 0.0f, 1.0f);
@@ -1550,7 +1570,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hitinfo(RtSceneDev sc, uint32_t ro
         const float4 A = q.rayA[0][i], B = q.rayB[0][i];
         const float2 hrec = q.hits[i];
         const uint32_t id = __float_as_uint(hrec.y);
-        const uint32_t sample = __float_as_uint(B.w) & RT_SAMPLE_MASK;
+        const uint32_t sample = __float_as_uint(B.w) & q.sample_mask;
         RtRay r{v3(A.x, A.y, A.z), v3(B.x, B.y, B.z)};
         rt_hit o;
         memset(&o, 0, sizeof o);
@@ -1599,8 +1619,7 @@ __global__ void k_rays_from_host(const float *rays, uint32_t n, RtQueues q) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         q.rayA[0][i] = make_float4(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2], 1.0f);
         q.rayB[0][i] = make_float4(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5], __uint_as_float(i));
-        q.rayR[0][i] = 1.0f;
-        if (i == 0) q.counters[RT_CNT_RAYS(0)] = n;
+        q.rayR[0][i] = 1.0f;  // (the queue's length is set by k_iter_ctl: the batch is the "chunk" that enters at iteration 0)
     }
 }
 
@@ -1626,42 +1645,47 @@ __global__ void k_eval_perlin(long long n, const float *p, float *out) {
 // and the kernels grid-stride over them, so a frame needs no host round trip between levels.
 static inline int gridFor(const RtLaunchCfg &cfg, int blocks_per_cu) { return cfg.num_cus * blocks_per_cu; }
 
-void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles) {
-    hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles);
+void rtLaunchIterCtl(const RtLaunchCfg &cfg, const RtQueues &q, int prev, uint32_t prim_next, bool set_cur, uint32_t prim_cur) {
+    hipLaunchKernelGGL(k_iter_ctl, dim3(1), dim3(64), 0, cfg.stream, q, prev, prim_next, set_cur ? 1 : 0, prim_cur);
 }
-// packets first (when the tree allows a wave-level stack), then the per-lane kernel over what they handed back
-// part: 0 = everything, 1 = only the packet kernel (if the level has one), 2 = only the per-lane kernels (so that the
-// caller can time the two separately)
-template <bool ANY>
-static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part) {
-    const size_t lds = (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes;
-    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
-    const uint32_t budget = ANY && q.split_cap ? (uint32_t)cfg.split_budget : 0u;
-#define RT_LAUNCHC(S, M) hipLaunchKernelGGL((k_closest<S, M>), grid, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries)
-#define RT_LAUNCHA(S, M, G, R, B)                                                                                                       \
-    do {                                                                                                                                \
-        if (level == 0 && q.occ0) hipLaunchKernelGGL((k_any<S, M, true>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B); \
-        else hipLaunchKernelGGL((k_any<S, M, false>), G, block, lds, cfg.stream, sc, root_ref, q, level, cfg.stack_entries, R, B);       \
-    } while (0)
-#define RT_LAUNCHP(A, S) hipLaunchKernelGGL((k_packet<A, S>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, level)
+void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, int par, uint32_t tile0, uint32_t ntiles) {
+    hipLaunchKernelGGL(k_gen_primary, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, f, q, par, tile0, ntiles);
+}
 // (stats: 0 = plain, 1 = counters, 2 = counters + wave-time profile)
 #define RT_BY_STATS(CALL) do { if (stats >= 2) { CALL(2); } else if (stats == 1) { CALL(1); } else { CALL(0); } } while (0)
-#define RT_PK(S) RT_LAUNCHP(ANY, (S) != 0)
-#define RT_A_RESID(S) RT_LAUNCHA(S, RT_MODE_RESID, grid, -1, budget)
+static inline size_t traceLds(const RtLaunchCfg &cfg) { return (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes; }
+// the iteration's primary rays (entries [0, q.prim_n) of ray queue `par`) as packets
+void rtLaunchPacket(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
+    const dim3 block(RT_BLOCK);
+    if (stats) hipLaunchKernelGGL((k_packet<true>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, par);
+    else hipLaunchKernelGGL((k_packet<false>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, par);
+}
+// per-lane closest-hit walks: resid = the primary rays the packet kernel handed over, else entries [first, n) of the queue
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stats, bool resid) {
+    const size_t lds = traceLds(cfg);
+    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
+#define RT_C_RESID(S) hipLaunchKernelGGL((k_closest<S, RT_MODE_RESID>), grid, block, lds, cfg.stream, sc, root_ref, q, par, 0u, cfg.stack_entries)
+#define RT_C_QUEUE(S) hipLaunchKernelGGL((k_closest<S, RT_MODE_QUEUE>), grid, block, lds, cfg.stream, sc, root_ref, q, par, first, cfg.stack_entries)
+    if (resid) RT_BY_STATS(RT_C_RESID); else RT_BY_STATS(RT_C_QUEUE);
+#undef RT_C_RESID
+#undef RT_C_QUEUE
+}
+// the iteration's shadow queue, then the follow-up rounds over the work items of split walks
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
+    const size_t lds = traceLds(cfg);
+    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
+    const uint32_t budget = q.split_cap ? (uint32_t)cfg.split_budget : 0u;
+#define RT_LAUNCHA(S, M, G, R, B)                                                                                                     \
+    do {                                                                                                                              \
+        if (q.occ0) hipLaunchKernelGGL((k_any<S, M, true>), G, block, lds, cfg.stream, sc, root_ref, q, par, cfg.stack_entries, R, B);  \
+        else hipLaunchKernelGGL((k_any<S, M, false>), G, block, lds, cfg.stream, sc, root_ref, q, par, cfg.stack_entries, R, B);       \
+    } while (0)
 #define RT_A_QUEUE(S) RT_LAUNCHA(S, RT_MODE_QUEUE, grid, -1, budget)
-#define RT_C_RESID(S) RT_LAUNCHC(S, RT_MODE_RESID)
-#define RT_C_QUEUE(S) RT_LAUNCHC(S, RT_MODE_QUEUE)
-    if (rtLevelUsesPackets(cfg, level, ANY)) {
-        if (part != 2) RT_BY_STATS(RT_PK);
-        if (part == 1) return;
-        if (ANY) RT_BY_STATS(RT_A_RESID); else RT_BY_STATS(RT_C_RESID);
-    } else {
-        if (part == 1) return;
-        if (ANY) RT_BY_STATS(RT_A_QUEUE); else RT_BY_STATS(RT_C_QUEUE);
-    }
-    if (ANY && budget) {
-        // follow-up rounds over the work items of split walks (almost always none: their waves read a zero count and
-        // leave); a quarter of the grid is plenty, the last round walks whatever is left to the end
+    RT_BY_STATS(RT_A_QUEUE);
+#undef RT_A_QUEUE
+    if (budget) {
+        // follow-up rounds (almost always without work: their waves read a zero count and leave); a quarter of the grid is
+        // plenty, the last round walks whatever is left to the end
         const dim3 sgrid(gridFor(cfg, cfg.trace_blocks_per_cu >= 4 ? cfg.trace_blocks_per_cu / 4 : 1));
         for (int r = 0; r < RT_SPLIT_ROUNDS; r++) {
             // items get an eighth of the budget: a round then lasts ~0.15 ms and the items multiply faster
@@ -1671,46 +1695,29 @@ static void launchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t r
 #undef RT_A_SPLIT
         }
     }
-#undef RT_BY_STATS
-#undef RT_PK
-#undef RT_A_RESID
-#undef RT_A_QUEUE
-#undef RT_C_RESID
-#undef RT_C_QUEUE
-#undef RT_LAUNCHC
 #undef RT_LAUNCHA
-#undef RT_LAUNCHP
 }
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part) {
-    launchTrace<false>(cfg, sc, root_ref, q, level, stats, part);
-}
-void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int level, int stats, int part) {
-    launchTrace<true>(cfg, sc, root_ref, q, level, stats, part);
-}
-void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int level, int max_depth, int spp,
+#undef RT_BY_STATS
+void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int par, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs) {
-    // slab: at most an eighth of what a wave can receive, so that the unused tails stay a small part of the queues
-    const uint64_t waves = (uint64_t)rtShadeWaves(cfg);
-    uint32_t slab = 64;
-    while (slab < RT_SLAB_MAX && (uint64_t)slab * 16 * waves <= max_inputs) slab <<= 1;
-    if (cfg.shade_slab) slab = cfg.shade_slab;
+    const uint32_t slab = rtShadeSlab(cfg, max_inputs);
     const dim3 grid(rtShadeBlocks(cfg)), block(RT_BLOCK);
     // the fast instance first (it fills the general list), then -- only for scenes that hold spheres / cones, BMP-textured
     // or anisotropic materials -- the general instance over that list.  Both reserve slabs: the queue slack covers two
     // partly filled slabs per wave and queue (rt_abi.cpp: queueSizes).
-    if (prof) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
-    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+    if (prof) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
+    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
     if (sc.has_general) {
-        if (prof) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
-        else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, cfg.stream, sc, q, level, max_depth, spp, tile0, primid_tiles, slab);
+        if (prof) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
+        else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
     }
 }
-void rtLaunchFold0(const RtLaunchCfg &cfg, const RtQueues &q, uint32_t samples, int nlights) {
-    hipLaunchKernelGGL(k_fold0, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, q, samples, nlights);
+void rtLaunchFold0(const RtLaunchCfg &cfg, const RtQueues &q, int nlights) {
+    hipLaunchKernelGGL(k_fold0, dim3(gridFor(cfg, 8)), dim3(RT_BLOCK), 0, cfg.stream, q, nlights);
 }
-void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t tile0, uint32_t ntiles,
+void rtLaunchResolve(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, uint32_t sample0, uint32_t tile0, uint32_t ntiles,
                      uint8_t *rgb8_tiles, float *rgbf_tiles) {
-    hipLaunchKernelGGL(k_resolve, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, f, q, tile0, ntiles, rgb8_tiles, rgbf_tiles);
+    hipLaunchKernelGGL(k_resolve, dim3(gridFor(cfg, 4)), dim3(RT_BLOCK), 0, cfg.stream, f, q, sample0, tile0, ntiles, rgb8_tiles, rgbf_tiles);
 }
 void rtLaunchAssemble(const RtLaunchCfg &cfg, int width, int height, int world, long long tiles_per_rank, const void *t8,
                       const void *tf, const void *tp, void *o8, void *of, void *op) {

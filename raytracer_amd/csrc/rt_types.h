@@ -152,10 +152,13 @@ struct RtFrameDev {
 #define RT_ID_TRI_MASK 0x0FFFFFFFu            // triangle slot of a triangle id
 #define RT_GENERAL_HOLE 0xFFFFFFFFu  // unused slot of a wave's slab of the general list (RtQueues::general)
 
-// ray flags packed above the sample index (30 bits of sample index: a chunk holds up to 2^30 - 1 primary samples)
-#define RT_SAMPLE_MASK 0x3FFFFFFFu
+// A ray's tag word (rayB.w): the sample's slot in the accumulator ring in the low bits, the ray's level (bounce count)
+// above them, two flags on top.  How the 30 bits are split is decided per frame (RtQueues::sample_mask / level_shift):
+// depth 3 needs 2 level bits, which leaves 2^28 ring samples.
+#define RT_SAMPLE_MASK 0x3FFFFFFFu            // sample + level bits
 #define RT_FLAG_HAS_REFR_SIBLING 0x40000000u  // reflection ray whose refraction sibling sits in the next slot
 #define RT_SHADOW_HOLE 0xFFFFFFFFu            // w of a shadow record that holds no ray (unused slot of a k_shade slab)
+#define RT_SHADOW_L0 0x40000000u              // w of a shadow record: the ray left a level-0 hit (RtQueues::occ0)
 #ifndef RT_SLAB_MAX
 #define RT_SLAB_MAX 1024u                    // slots a k_shade wave reserves at a time, per light / for the next level
 #endif
@@ -168,8 +171,13 @@ struct RtFrameDev {
 #define RT_BLOCK 256                         // threads per block of every kernel
 #define RT_FLAG_INVALID 0x80000000u           // slot of a pixel outside the image or unused slab slot: traced as a miss, never shaded
 
-// Wavefront queues of one chunk (device pointers).  Rays: A = (origin.xyz, weight), B = (direction.xyz, sample|flags),
-// R = Fresnel reflectance to apply if the sibling hits.  Shadow rays: A = (shaded point, sample), L = light index,
+// Wavefront queues (device pointers).  The frame is rendered as a PIPELINE of chunks (rt_abi.cpp: runFrame): iteration i
+// traces and shades, in ONE pass per kernel, level 0 of chunk i, level 1 of chunk i-1, ... level D of chunk i-D.  The ray
+// queues ping-pong by iteration (iteration i reads buffer i & 1, its k_shade appends the next levels' rays to the other
+// one, behind the slots [0, prim_n) that the next chunk's primary rays occupy); every per-queue counter exists once per
+// parity.  Sample accumulators form a ring of D + 1 chunk-sized slots.
+// Rays: A = (origin.xyz, weight), B = (direction.xyz, tag: ring sample | level | flags), R = Fresnel reflectance to
+// apply if the sibling hits.  Shadow rays: A = (shaded point, ring sample | RT_SHADOW_L0), L = light index,
 // C = (pending rgb, 0); origin, direction and light distance are recomputed from the point (rtShadowRay).
 struct RtQueues {
     float4 *rayA[2];
@@ -178,60 +186,79 @@ struct RtQueues {
     float2 *hits;
     float4 *shA, *shC;
     uint8_t *shL;              // light index of a shadow record (one byte per slot)
-    long long *accum;          // [chunk samples][3] fixed point
+    long long *accum;          // [ring samples][3] fixed point
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
     uint32_t *resid;           // rays the packet kernels hand to the per-lane kernels (queue indices)
     uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap;
+    // this iteration (set by the host per launch): entries [0, prim_n) of the current ray queue are the primary rays of the
+    // chunk that enters the pipeline -- level 0, entry k belongs to ring sample prim_sample0 + k
+    uint32_t prim_n, prim_sample0;
+    uint32_t sample_mask;      // tag & sample_mask = ring sample
+    uint32_t level_shift, level_mask;  // (tag >> level_shift) & level_mask = level of the ray
     // Level-0 shadow results without atomics (null = off): a sample has ONE level-0 hit, hence at most one level-0 shadow
-    // ray per light, so k_any can STORE the radiance of an unoccluded one at [light][sample] (col0, flag in occ0) and
-    // k_fold0 adds them to the accumulator afterwards, one lane per sample.  Same fixed-point sums, same bits; pays where
-    // most shadow rays are level-0 rays that reach their light (the L2 retires only ~75 G atomics per second).
-    uint8_t *occ0;             // [light][l0_stride] 1 = col0 holds a contribution; cleared per chunk
+    // ray per light, so k_any can STORE the radiance of an unoccluded one at [light][sample - prim_sample0] (col0, flag
+    // in occ0) and k_fold0 adds them to the accumulator afterwards, one lane per sample.  Same fixed-point sums, same bits;
+    // pays where most shadow rays are level-0 rays that reach their light (the L2 retires only ~75 G atomics per second).
+    uint8_t *occ0;             // [light][l0_stride] 1 = col0 holds a contribution; cleared per iteration
     float4 *col0;              // [light][l0_stride]
-    uint32_t l0_stride;        // samples of the chunk
+    uint32_t l0_stride;        // samples of a chunk
 };
 
 // Device counters.  Every hot counter owns a 128-byte line: returning atomics on one line serialise at the memory
-// side (~10 ns each), so queue heads that are bumped from every CU must not share a line.
+// side (~10 ns each), so queue heads that are bumped from every CU must not share a line.  `p` is the parity of the
+// iteration (0 / 1) the queue belongs to.
 #define RT_CNT_STRIDE 32
-#define RT_CNT_RAYS(d) ((d) * RT_CNT_STRIDE)                 // rays queued for level d (d = 0..15)
-#define RT_CNT_SHADOW(d) ((16 + (d)) * RT_CNT_STRIDE)        // shadow rays of level d
-#define RT_CNT_CULLED (32 * RT_CNT_STRIDE)
-#define RT_CNT_SHADED (33 * RT_CNT_STRIDE)
-#define RT_CNT_OVERFLOW (34 * RT_CNT_STRIDE)
-#define RT_CNT_INVALID (35 * RT_CNT_STRIDE)                  // level-0 slots outside the image (ragged edge tiles)
-#define RT_CNT_NODES (36 * RT_CNT_STRIDE)                    // u64 nodes at +0, u64 triangle tests at +2, u32 longest walk at +4 (closest rays)
-#define RT_CNT_ANY_NODES (37 * RT_CNT_STRIDE)                // same for shadow rays
-#define RT_CNT_PROF_CLOSEST (38 * RT_CNT_STRIDE)             // 10 x u64 wave-time breakdown of k_closest (stats build)
-#define RT_CNT_PROF_ANY (39 * RT_CNT_STRIDE)                 // same for k_any
-#define RT_CNT_WORK_CLOSEST(d) ((40 + (d)) * RT_CNT_STRIDE)  // next unclaimed entry of level d's ray queue (dynamic fetch)
-#define RT_CNT_WORK_ANY(d) ((56 + (d)) * RT_CNT_STRIDE)      // same for level d's shadow queue
-#define RT_CNT_PROF_SHADE (72 * RT_CNT_STRIDE)               // 6 x u64 wave-time breakdown of k_shade (stats build)
-#define RT_CNT_PROF_PACKET_CLOSEST (73 * RT_CNT_STRIDE)      // 8 x u64 packet statistics of k_packet<closest> (stats build)
-#define RT_CNT_PROF_PACKET_ANY (74 * RT_CNT_STRIDE)          // same for shadow packets
-#define RT_CNT_SHADOW_HOLES (75 * RT_CNT_STRIDE)             // unused slab slots of the shadow queues (not rays)
-#define RT_CNT_GENERAL(d) (75 * RT_CNT_STRIDE + 12 + (d))     // hits of level d left to the general k_shade (d = 0..15)
-#define RT_CNT_ZERO (75 * RT_CNT_STRIDE + 8)                 // shadow rays not emitted because their pending radiance is exactly zero
-#define RT_CNT_UNOCCLUDED (75 * RT_CNT_STRIDE + 4)           // u64: shadow rays that reached their light (stats build)
-#define RT_CNT_RESID_CLOSEST(d) ((76 + (d)) * RT_CNT_STRIDE) // rays of level d handed to the per-lane closest-hit kernel
-#define RT_CNT_RESID_ANY(d) ((92 + (d)) * RT_CNT_STRIDE)     // same for shadow rays
-#define RT_CNT_PWORK_CLOSEST(d) ((108 + (d)) * RT_CNT_STRIDE) // next unclaimed packet batch of level d (packet kernels)
-#define RT_CNT_PWORK_ANY(d) ((124 + (d)) * RT_CNT_STRIDE)
-// cursors of the parts a level's queue is cut into for the dynamic fetch (one 128-byte line each)
+#define RT_CNT_RAYS(p) ((p) * RT_CNT_STRIDE)                 // entries of ray queue p (primary slots + appended bounce rays + slab holes)
+#define RT_CNT_SHADOW(p) ((2 + (p)) * RT_CNT_STRIDE)         // entries of the shadow queue of iteration parity p
+#define RT_CNT_CULLED (4 * RT_CNT_STRIDE)
+#define RT_CNT_SHADED (5 * RT_CNT_STRIDE)
+#define RT_CNT_OVERFLOW (6 * RT_CNT_STRIDE)
+#define RT_CNT_INVALID (7 * RT_CNT_STRIDE)                   // ray-queue slots that hold no ray: pixels outside the image (ragged edge tiles), unused slab slots
+#define RT_CNT_NODES (8 * RT_CNT_STRIDE)                     // u64 nodes at +0, u64 triangle tests at +2, u32 longest walk at +4 (closest rays)
+#define RT_CNT_ANY_NODES (9 * RT_CNT_STRIDE)                 // same for shadow rays
+#define RT_CNT_PROF_CLOSEST (10 * RT_CNT_STRIDE)             // 10 x u64 wave-time breakdown of k_closest (stats build)
+#define RT_CNT_PROF_ANY (11 * RT_CNT_STRIDE)                 // same for k_any
+#define RT_CNT_PROF_SHADE (12 * RT_CNT_STRIDE)               // 6 x u64 wave-time breakdown of k_shade (stats build)
+#define RT_CNT_PROF_PACKET (13 * RT_CNT_STRIDE)              // 8 x u64 packet statistics of k_packet (stats build)
+#define RT_CNT_SHADOW_HOLES (14 * RT_CNT_STRIDE)             // unused slab slots of the shadow queues (not rays)
+#define RT_CNT_ZERO (14 * RT_CNT_STRIDE + 8)                 // shadow rays not emitted because their pending radiance is exactly zero
+#define RT_CNT_UNOCCLUDED (14 * RT_CNT_STRIDE + 4)           // u64: shadow rays that reached their light (stats build)
+#define RT_CNT_SHADOW_L0 (14 * RT_CNT_STRIDE + 12)           // shadow rays emitted by level-0 hits (decides RtQueues::occ0)
+#define RT_CNT_GENERAL(p) ((15 + (p)) * RT_CNT_STRIDE)       // hits of iteration parity p left to the general k_shade
+#define RT_CNT_RESID(p) ((17 + (p)) * RT_CNT_STRIDE)         // primary rays the packet kernel handed to the per-lane closest-hit kernel
+#define RT_CNT_PWORK(p) ((19 + (p)) * RT_CNT_STRIDE)         // next unclaimed packet batch (packet kernel)
+#define RT_CNT_WORK_RESID(p) ((21 + (p)) * RT_CNT_STRIDE)    // next unclaimed entry of the hand-over list
+// Frame totals (u64 each, one line): k_iter_ctl moves the per-iteration 32-bit counters here after every iteration, so
+// that no 32-bit counter has to hold more than one iteration's worth
+#define RT_CNT_TOTALS (23 * RT_CNT_STRIDE)
+#define RT_TOT_RAYS 0          // ray-queue entries (incl. slots that hold no ray: RT_TOT_INVALID)
+#define RT_TOT_SHADOW 1        // shadow-queue entries (incl. RT_TOT_SHADOW_HOLES)
+#define RT_TOT_CULLED 2
+#define RT_TOT_SHADED 3
+#define RT_TOT_OVERFLOW 4
+#define RT_TOT_INVALID 5
+#define RT_TOT_SHADOW_HOLES 6
+#define RT_TOT_ZERO 7
+#define RT_TOT_SPLIT 8         // work items of split any-hit walks
+#define RT_TOT_MAX_RAYS 9      // fullest ray queue / shadow queue of the frame, in entries
+#define RT_TOT_MAX_SHADOW 10
+#define RT_TOT_SHADOW_L0 11    // shadow rays emitted by level-0 hits
+#define RT_TOT_WORDS 12
+// cursors of the parts a queue is cut into for the dynamic fetch (one 128-byte line each)
 #ifndef RT_WORK_PARTS
 #define RT_WORK_PARTS 8
 #endif
-#define RT_CNT_WORKP_CLOSEST(d, p) (RT_CNT_WORKP_BASE + ((d) * RT_WORK_PARTS + (p)) * RT_CNT_STRIDE)
-#define RT_CNT_WORKP_ANY(d, p) (RT_CNT_WORKP_BASE + ((16 + (d)) * RT_WORK_PARTS + (p)) * RT_CNT_STRIDE)
-// split rounds of the shadow kernels (rt_kernels.hip, "long any-hit walks"): per level and round the number of work
+#define RT_CNT_WORKP_BASE (24 * RT_CNT_STRIDE)
+#define RT_CNT_WORKP_CLOSEST(p, k) (RT_CNT_WORKP_BASE + ((p) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)
+#define RT_CNT_WORKP_ANY(p, k) (RT_CNT_WORKP_BASE + ((2 + (p)) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)
+// split rounds of the shadow kernels (rt_kernels.hip, "long any-hit walks"): per parity and round the number of work
 // items queued for it (+0) and the next unclaimed one (+1)
 #define RT_SPLIT_ROUNDS 6
-#define RT_CNT_SPLIT(level, round) (140 * RT_CNT_STRIDE + ((level) * (RT_SPLIT_ROUNDS + 1) + (round)) * 2)
-#define RT_CNT_WORKP_BASE ((140 + 8) * RT_CNT_STRIDE)  // (16 levels x 7 rounds x 2 words of RT_CNT_SPLIT fit 7 strides)
-#define RT_CNT_WORDS (RT_CNT_WORKP_BASE + 32 * RT_WORK_PARTS * RT_CNT_STRIDE)
+#define RT_CNT_SPLIT_BASE (RT_CNT_WORKP_BASE + 4 * RT_WORK_PARTS * RT_CNT_STRIDE)
+#define RT_CNT_SPLIT(p, round) (RT_CNT_SPLIT_BASE + ((p) * (RT_SPLIT_ROUNDS + 1) + (round)) * 2)
+#define RT_CNT_WORDS (RT_CNT_SPLIT_BASE + RT_CNT_STRIDE)  // (2 parities x 7 rounds x 2 words fit one stride)
 #define RT_SPLIT_NULL 0xFFFFFFFFu     // ray index of an item that holds no work (reserved slots of a wave that could not export)
 #define RT_JOIN_OCCLUDED 0x80000000u  // join word of a split shadow ray (shC.w as u32): outstanding items | this flag
-
