@@ -179,6 +179,11 @@ def main():
         kinds = {
             "k_closest": (timed["ms_closest"], timed["launches_closest"], counted["nodes_visited"], counted["tris_tested"], counted["rays_closest"]),
             "k_any": (timed["ms_any"], timed["launches_any"], counted["nodes_visited_any"], counted["tris_tested_any"], counted["rays_shadow"]),
+            # the fused traversal launch (one per iteration): shadow rays + bounce rays per lane, primary rays as packets
+            # (a packet step is counted once per lane that takes part in it: prof_packet[2] / [4])
+            "k_trace": (timed["ms_trace"], max(timed["launches_closest"], timed["launches_any"]),
+                        counted["nodes_visited"] + counted["nodes_visited_any"] + pc[2],
+                        counted["tris_tested"] + counted["tris_tested_any"] + pc[4], counted["rays_closest"] + counted["rays_shadow"]),
         }
         name = max(kinds, key=lambda k: kinds[k][0])
         ms, launches, nodes, tris, nrays = kinds[name]
@@ -191,6 +196,8 @@ def main():
         # light; k_closest: 32 B ray record + 8 B hit record per ray
         if name == "k_any":
             qbytes = 16.0 * nrays + 40.0 * counted["shadow_unoccluded"]
+        elif name == "k_trace":
+            qbytes = 16.0 * counted["rays_shadow"] + 40.0 * counted["shadow_unoccluded"] + 40.0 * counted["rays_closest"]
         else:
             qbytes = 40.0 * nrays
         khash = kernel_source_hash()
@@ -214,7 +221,7 @@ def main():
                     "note": "queue records + accumulator updates only; BVH / triangle records are L2 / Infinity Cache resident"},
             "note": "no dense contraction on this path (SURVEY.md 8d): the ceiling is the FP32 vector unit; flops = 80 per 4-wide "
                     "node step + 80 per triangle test, both counted in-kernel in this run"}
-        pr = counted["prof_any" if name == "k_any" else "prof_closest"]  # counted in-kernel (cheap statistics build)
+        pr = counted["prof_any" if name == "k_any" else "prof_closest"]  # counted in-kernel (cheap statistics build; k_trace: its closest-hit phase)
         if pr[2] and pr[5] and pr[8]:
             result["roofline"]["lanes"] = {
                 "lanes_per_node_phase": pr[3] / pr[2], "lanes_per_triangle_phase": pr[6] / pr[5],
@@ -229,7 +236,7 @@ def main():
                     "valu_wave_insts_per_ray": v["SQ_INSTS_VALU"] / max(nrays, 1),
                     "valu_issue_frac_of_2cyc_peak": v.get("valu_issue_frac"), "sclk_ghz_profiled": v.get("sclk_ghz"),
                     "source": "profiles/r02_pmc_valu.json (same kernel sources); see profiles/r02_valu_issue.md"}
-        result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_packet", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
+        result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_trace", "ms_packet", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
     if rank == 0 and not a.no_cpu and world == 1:
         try:
             sw, sh = (int(x) for x in a.cpu_sample.split("x"))

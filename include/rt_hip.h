@@ -138,8 +138,11 @@ typedef struct rt_stats {
                                    pending radiance is exactly zero (e.g. main.cpp:172 with refraction 1): rays_shadow + shadow_zero
                                    is the reference's shadow-ray count */
     uint64_t chunks;            /* chunks of whole tiles the frame was rendered in (including repeated ones) */
-    uint64_t chunk_retries;     /* chunks whose queues, sized from the fan-out seen so far, overflowed and that were rendered
-                                   again with worst-case queues (results are those of the repeat; 0 in steady state) */
+    uint64_t chunk_retries;     /* chunks of a frame whose queues, sized from the fan-out seen so far, overflowed: the frame was
+                                   rendered again with worst-case queues (results are those of the repeat; 0 in steady state) */
+    double ms_trace;            /* the fused traversal launches (k_trace: shadow rays of an iteration + bounce rays and primary
+                                   packets of the next; collect_stats & 2).  ms_any / ms_closest / ms_packet are then the split
+                                   rounds / 0 / 0; RT_FUSE=0 launches the phases separately and fills those instead */
 } rt_stats;
 
 /* A closest-hit record as the reference's `Hit` (Core.h:34-57) plus primitive identity. 96 bytes. */

@@ -60,7 +60,7 @@ class Stats(C.Structure):
         ("nodes_visited_any", C.c_uint64), ("tris_tested_any", C.c_uint64), ("bvh_max_stack", C.c_uint64), ("prof_closest", C.c_uint64 * 10), ("prof_any", C.c_uint64 * 10), ("prof_shade", C.c_uint64 * 6), ("prof_packet_closest", C.c_uint64 * 8), ("prof_packet_any", C.c_uint64 * 8),
         ("max_walk_closest", C.c_uint64), ("max_walk_any", C.c_uint64),
         ("ms_packet", C.c_double), ("shadow_unoccluded", C.c_uint64), ("split_items", C.c_uint64), ("shadow_zero", C.c_uint64),
-        ("chunks", C.c_uint64), ("chunk_retries", C.c_uint64),
+        ("chunks", C.c_uint64), ("chunk_retries", C.c_uint64), ("ms_trace", C.c_double),
     ]
 
     def as_dict(self):

@@ -43,7 +43,8 @@ QueueSizes queueSizes(const RtLaunchCfg &cfg, size_t samples, double ray_fan, do
     const size_t slabR = std::max<size_t>(z.slab, 128);
     z.ray_cap = rays + 2 * waves * slabR + rays / 64 + 128;
     z.sh_cap = shadows + 2 * waves * (size_t)nl * z.slab;
-    z.fits32 = z.ray_cap < (1ull << 32) - 2048 && z.sh_cap < (1ull << 32) - 2048;
+    // (k_shade's segment cursor and the traversal cursors run past the end of a queue by up to one fetch per wave)
+    z.fits32 = z.ray_cap < (1ull << 32) - (1ull << 26) && z.sh_cap < (1ull << 32) - (1ull << 26);
     return z;
 }
 
@@ -76,7 +77,6 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     q.shC = (float4 *)take(c.sh_cap * sizeof(float4));
     q.shL = (uint8_t *)take(c.sh_cap);
     q.accum = (long long *)take((size_t)c.ring * c.samples * 3 * sizeof(long long));
-    q.resid = (uint32_t *)take(c.samples * sizeof(uint32_t));  // only primary rays go through the packet kernel
     q.general = (uint32_t *)take(c.ray_cap * sizeof(uint32_t));
     if (c.l0) {
         q.occ0 = (uint8_t *)take(c.samples * (size_t)c.nl);
@@ -181,7 +181,7 @@ struct KernelTimer {  // optional per-kernel-class timing with HIP events on the
         if (!on) return;
         (void)hipEventRecord(spans.back().b, stream);
     }
-    void collect(double *ms /*[6]*/) {
+    void collect(double *ms /*[7]*/) {
         for (Span &s : spans) {
             float t = 0;
             (void)hipEventElapsedTime(&t, s.a, s.b);
@@ -236,41 +236,13 @@ void addCounters(rt_stats *st, const uint32_t *c) {
     for (int k = 0; k < 8; k++) st->prof_packet_closest[k] += u64at(RT_CNT_PROF_PACKET + 2 * k);  // (prof_packet_any: no shadow packets)
 }
 
-// One iteration on ray queue `par`, behind k_iter_ctl (and k_gen_primary where a chunk enters): closest hits, shading,
-// shadow rays.  q.prim_n / q.prim_sample0 describe the entering chunk (0 = none).  closest_done: the caller has traced
-// the whole queue already (rt_trace_batch reports the hit records of its rays from that pass).
-void launchIteration(rt_context *ctx, const RtLaunchCfg &cfg, const RtQueues &q, int par, bool has_bounce, bool closest_done, int max_depth,
-                     int spp, uint32_t tile0, uint32_t *primid_tiles, int stats, KernelTimer &kt, rt_stats *st, uint64_t max_inputs) {
-    const bool pk = cfg.packets && q.prim_n > 0;
-    if (!closest_done) {
-        if (pk) {  // the primary rays as packets, then per lane what the packet kernel handed back
-            kt.begin(5);
-            rtLaunchPacket(cfg, ctx->dev, ctx->bvh.root_ref, q, par, stats);
-            kt.end();
-            kt.begin(1);
-            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0u, stats, true);
-            kt.end();
-        }
-        if (!pk || has_bounce) {
-            kt.begin(1);
-            rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, par, pk ? q.prim_n : 0u, stats, false);
-            kt.end();
-            if (st) st->launches_closest++;  // (launches that walk a queue: what a kernel trace lists as k_closest<.., 0>)
-        }
-    }
-    kt.begin(2);
-    rtLaunchShade(cfg, ctx->dev, q, par, max_depth, spp, tile0, primid_tiles, stats >= 2, max_inputs);
-    kt.end();
-    kt.begin(3);
-    rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, par, stats);
-    if (q.occ0 && q.prim_n) rtLaunchFold0(cfg, q, (int)ctx->lights.size());
-    kt.end();
-    if (st) st->launches_any++;
-}
-
-// Enqueues a whole frame on cfg.stream: no host synchronisation, no allocation.
+// Enqueues a whole frame on cfg.stream: no host synchronisation, no allocation.  Launch order (S = k_shade, A = shadow
+// rays, C = bounce rays, P = primary packets, the index is the iteration = the ray queue):
+//     ctl(0) gen(0) [C|P](0)   then per iteration j:   ctl(j) S(j) gen(j+1) [A(j)|C(j+1)|P(j+1)] splits(j) fold0(j) resolve(j-D)
+// A(j), C(j+1) and P(j+1) only depend on S(j) / gen(j+1), so they share ONE persistent launch (k_trace) whose waves go
+// from one to the next at their own pace.  `fuse` = false launches them one after the other (per-kernel timing, RT_FUSE=0).
 int enqueueFrame(rt_context *ctx, const RtLaunchCfg &cfg, const RtFrameDev &f, const FramePlan &pl, const RtQueues &q0, int max_depth,
-                 size_t n_local, size_t per_tile, uint8_t *d_rgb8, float *d_rgbf, uint32_t *d_primid, int stats, KernelTimer &kt,
+                 size_t n_local, size_t per_tile, uint8_t *d_rgb8, float *d_rgbf, uint32_t *d_primid, int stats, bool fuse, KernelTimer &kt,
                  rt_stats *st) {
     hipStream_t stream = cfg.stream;
     // the workspace keeps the last frame's contents: counters, work cursors and totals start at zero; queues and sample
@@ -280,27 +252,74 @@ int enqueueFrame(rt_context *ctx, const RtLaunchCfg &cfg, const RtFrameDev &f, c
     if (d_primid && n_local) HIPOK(hipMemsetAsync(d_primid, 0xFF, n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
     if (n_local == 0) return 0;
     const size_t nchunks = pl.nchunks, T = nchunks + (size_t)max_depth;
+    const uint32_t root = ctx->bvh.root_ref;
+    const int nlights = (int)ctx->lights.size();
     auto ntilesOf = [&](size_t c) { return (uint32_t)std::min(pl.tiles, n_local - c * pl.tiles); };
+    auto primN = [&](size_t j) { return j < nchunks ? ntilesOf(j) * (uint32_t)per_tile : 0u; };
+    auto sample0 = [&](size_t c) { return (uint32_t)((c % (size_t)pl.ring) * pl.samples); };
     const uint64_t max_inputs = (uint64_t)std::ceil((double)pl.samples * pl.ray_fan);
-    for (size_t j = 0; j < T; j++) {
-        const int par = (int)(j & 1);
-        const bool entering = j < nchunks;
+    // queue j's primary rays (if a chunk enters at j) and closest hits: everything k_shade(j) will read
+    auto enter = [&](size_t j, int par_any) {  // par_any: the shadow queue walked next to it (-1: none)
         RtQueues q = q0;
-        q.prim_n = entering ? ntilesOf(j) * (uint32_t)per_tile : 0u;
-        q.prim_sample0 = entering ? (uint32_t)((j % (size_t)pl.ring) * pl.samples) : 0u;
-        const uint32_t prim_next = j + 1 < nchunks ? ntilesOf(j + 1) * (uint32_t)per_tile : 0u;
-        rtLaunchIterCtl(cfg, q, par ^ 1, prim_next, j == 0, q.prim_n);
-        const uint32_t tile0 = (uint32_t)(j * pl.tiles);
-        if (entering) {
+        q.prim_n = primN(j);
+        q.prim_sample0 = j < nchunks ? sample0(j) : 0u;
+        q.l0_sample0 = j >= 1 && j - 1 < nchunks ? sample0(j - 1) : 0u;  // (the shadow rays are those of iteration j - 1)
+        const int par = (int)(j & 1);
+        if (q.prim_n) {
             kt.begin(0);
-            rtLaunchGenPrimary(cfg, f, q, par, tile0, ntilesOf(j));
+            rtLaunchGenPrimary(cfg, f, q, par, (uint32_t)(j * pl.tiles), ntilesOf(j));
             kt.end();
         }
-        launchIteration(ctx, cfg, q, par, j > 0 && max_depth > 0, false, max_depth, f.spp, tile0, d_primid, stats, kt, st, max_inputs);
+        const bool pk = cfg.packets && q.prim_n > 0, queue_j = j < T;
+        const uint32_t first = pk ? q.prim_n : 0u;
+        if (fuse) {
+            if (par_any < 0 && !queue_j) return;
+            kt.begin(6);
+            rtLaunchTrace(cfg, ctx->dev, root, q, par_any, queue_j ? par : -1, first, pk, stats);
+            kt.end();
+        } else {
+            if (par_any >= 0) {
+                kt.begin(3);
+                rtLaunchAny(cfg, ctx->dev, root, q, par_any, stats);
+                kt.end();
+            }
+            if (queue_j && (j > 0 || !pk)) {
+                kt.begin(1);
+                rtLaunchClosest(cfg, ctx->dev, root, q, par, first, stats);
+                kt.end();
+            }
+            if (pk) {
+                kt.begin(5);
+                rtLaunchPacket(cfg, ctx->dev, root, q, par, stats);
+                kt.end();
+            }
+        }
+        if (st) {  // (launches that walk a queue; a fused launch walks one of each kind)
+            if (queue_j) st->launches_closest++;
+            if (par_any >= 0) st->launches_any++;
+        }
+    };
+    rtLaunchIterCtl(cfg, q0, 1, primN(1), true, primN(0));
+    enter(0, -1);
+    for (size_t j = 0; j < T; j++) {
+        const int par = (int)(j & 1);
+        RtQueues q = q0;
+        q.prim_n = primN(j);
+        q.prim_sample0 = j < nchunks ? sample0(j) : 0u;
+        q.l0_sample0 = q.prim_sample0;
+        if (j > 0) rtLaunchIterCtl(cfg, q, par ^ 1, primN(j + 1), false, 0u);
+        kt.begin(2);
+        rtLaunchShade(cfg, ctx->dev, q, par, max_depth, f.spp, (uint32_t)(j * pl.tiles), d_primid, stats >= 2, max_inputs);
+        kt.end();
+        enter(j + 1, par);
+        kt.begin(3);
+        rtLaunchSplitRounds(cfg, ctx->dev, root, q, par, stats);
+        if (q.occ0 && q.prim_n) rtLaunchFold0(cfg, q, nlights);
+        kt.end();
         if (j >= (size_t)max_depth) {  // the chunk whose deepest level was just shaded and whose last shadow rays were traced
             const size_t c = j - (size_t)max_depth;
             kt.begin(4);
-            rtLaunchResolve(cfg, f, q, (uint32_t)((c % (size_t)pl.ring) * pl.samples), (uint32_t)(c * pl.tiles), ntilesOf(c), d_rgb8, d_rgbf);
+            rtLaunchResolve(cfg, f, q, sample0(c), (uint32_t)(c * pl.tiles), ntilesOf(c), d_rgb8, d_rgbf);
             kt.end();
         }
     }
@@ -394,6 +413,8 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     double ws_gb = 24.0, ws_frac = 0.875;
     if (const char *e = getenv("RT_WORKSPACE_GB")) ws_gb = std::max(0.001, atof(e));
     if (const char *e = getenv("RT_WORKSPACE_FRACTION")) ws_frac = std::min(0.875, std::max(0.01, atof(e)));
+    bool fuse = true;  // RT_FUSE=0: the traversal phases of an iteration as launches of their own (ms_any / ms_closest / ms_packet)
+    if (const char *e = getenv("RT_FUSE")) fuse = atoi(e) != 0;
     std::vector<uint32_t> hc(RT_CNT_WORDS, 0);
     bool started = false;  // ev.a is recorded once the workspace exists: ms_total is GPU time, not hipMalloc time
     for (int attempt = 0;; attempt++) {
@@ -437,7 +458,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
             started = true;
         }
         rt_stats launches{};
-        if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, per_tile, d_rgb8, d_rgbf, d_primid, stats_on, kt, &launches)) return 1;
+        if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, per_tile, d_rgb8, d_rgbf, d_primid, stats_on, fuse, kt, &launches)) return 1;
         HIPOK(hipMemcpyAsync(hc.data(), q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPOK(hipEventRecord(ev.b, stream));
         HIPOK(hipStreamSynchronize(stream));
@@ -464,7 +485,10 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
             const double sall = (double)(tot[RT_TOT_SHADOW] - tot[RT_TOT_SHADOW_HOLES]);
             ctx->obs_l0_share = sall > 0 ? (double)tot[RT_TOT_SHADOW_L0] / sall : 0.0;
             if (getenv("RT_VERBOSE"))
-                std::fprintf(stderr, "[rt] frame done: %.2f rays + %.2f shadow rays per sample in flight, level-0 share of the shadow rays %.2f\n", r, sh, ctx->obs_l0_share);
+                std::fprintf(stderr, "[rt] frame done: %.2f rays + %.2f shadow rays per sample in flight, level-0 share of the shadow rays %.2f; "
+                             "queue slots without a ray: %.1f %% of the ray queues, %.1f %% of the shadow queues\n", r, sh, ctx->obs_l0_share,
+                             100.0 * (double)tot[RT_TOT_INVALID] / std::max(1.0, (double)tot[RT_TOT_RAYS]),
+                             100.0 * (double)tot[RT_TOT_SHADOW_HOLES] / std::max(1.0, (double)tot[RT_TOT_SHADOW]));
             if (!ctx->obs_valid) ctx->obs_ray = ctx->obs_sh = 0.0;
             ctx->obs_ray = std::max(ctx->obs_ray, std::max(r, 1.0));
             ctx->obs_sh = std::max(ctx->obs_sh, sh);
@@ -476,10 +500,11 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     float ms = 0;
     HIPOK(hipEventElapsedTime(&ms, ev.a, ev.b));
     st->ms_total = ms;
-    double cls[6] = {0, 0, 0, 0, 0, 0};
+    double cls[7] = {0, 0, 0, 0, 0, 0, 0};
     kt.collect(cls);
     st->ms_gen = cls[0]; st->ms_closest = cls[1]; st->ms_shade = cls[2]; st->ms_any = cls[3]; st->ms_resolve = cls[4];
     st->ms_packet = cls[5];
+    st->ms_trace = cls[6];
     // primary samples = valid pixels of this rank's tiles x spp
     {
         uint64_t pix = 0;
@@ -531,7 +556,7 @@ int renderTilesStatic(rt_context *ctx, const rt_camera *cam, const rt_render_par
     RtQueues q;
     carveQueues((unsigned char *)ctx->scratch, pl.spec, ctx->d_spill.p, q);
     KernelTimer kt;  // (off)
-    if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, kt, nullptr)) return 1;
+    if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, true, kt, nullptr)) return 1;
     HIPOK(hipGetLastError());
     return 0;
 }
@@ -569,7 +594,6 @@ int traceBatch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, flo
     DevBuf<float> d_rays, d_col;
     DevBuf<rt_hit> d_hits;
     DevBuf<uint8_t> d_sh;
-    KernelTimer kt;
     int rc = 0;
     std::vector<uint32_t> hc(RT_CNT_WORDS);
     for (int64_t off = 0; off < n && !rc; off += (int64_t)chunk) {
@@ -579,24 +603,27 @@ int traceBatch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, flo
         hipError_t e = hipMemcpyAsync(d_rays.p, rays + 6 * off, (size_t)m * 6 * sizeof(float), hipMemcpyHostToDevice, cfg.stream);
         if (e == hipSuccess) e = hipMemsetAsync(q0.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), cfg.stream);
         if (e != hipSuccess) { rc = fail(hipGetErrorString(e)); break; }
-        for (int j = 0; j <= depth; j++) {
+        for (int j = 0; j <= depth; j++) {  // one chunk: the levels one after the other, every phase a launch of its own
             const int par = j & 1;
             RtQueues q = q0;
             q.prim_n = j == 0 ? m : 0u;
             q.prim_sample0 = 0;
+            q.l0_sample0 = 0;
             rtLaunchIterCtl(cfg, q, par ^ 1, 0u, j == 0, q.prim_n);
             if (j == 0) {
                 rtLaunchRaysFromHost(cfg, d_rays.p, m, q);
-                // closest hit of the batch first: its hit records are reported from this pass
-                if (cfg.packets) {
-                    rtLaunchPacket(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0);
-                    rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0u, 0, true);
-                } else {
-                    rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0u, 0, false);
-                }
+                if (cfg.packets) rtLaunchPacket(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0);
+                else rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0u, 0);
+                // the closest hits of the batch are reported from this pass
                 if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
+            } else {
+                rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0u, 0);
             }
-            launchIteration(ctx, cfg, q, par, j > 0, j == 0, depth, 1, 0, nullptr, 0, kt, st, (uint64_t)m << j);
+            rtLaunchShade(cfg, ctx->dev, q, par, depth, 1, 0, nullptr, false, (uint64_t)m << j);
+            rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0);
+            rtLaunchSplitRounds(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0);
+            st->launches_closest++;
+            st->launches_any++;
         }
         rtLaunchIterCtl(cfg, q0, depth & 1, 0u, false, 0u);
         rtLaunchBatchColors(cfg, q0, m, d_col.p);

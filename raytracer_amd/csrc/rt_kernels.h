@@ -22,9 +22,14 @@ struct RtLaunchCfg {
 void rtLaunchIterCtl(const RtLaunchCfg &cfg, const RtQueues &q, int prev, uint32_t prim_next, bool set_cur, uint32_t prim_cur);
 void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQueues &q, int par, uint32_t tile0, uint32_t ntiles);
 // stats: 0 plain, 1 counters, 2 + wave-time profile
+// the fused traversal launch: shadow queue par_any, bounce rays [first, n) of ray queue par_closest and its primary rays
+// [0, q.prim_n) as packets (a parity < 0 skips the phase); then the same phases as launches of their own
+void rtLaunchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par_any, int par_closest,
+                   uint32_t first, bool packets, int stats);
 void rtLaunchPacket(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stats, bool resid);
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stats);
 void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
+void rtLaunchSplitRounds(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int par, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs);
 // waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)

@@ -469,31 +469,41 @@ RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, uint32_t light, RtRay &r
 // (MODE 2) walk the items with all lanes, exporting again what is still long; the last one has no budget.  The ray's
 // join word (shC.w as u32) counts its outstanding items; an item that finds a hit sets RT_JOIN_OCCLUDED; the item
 // that brings the count to zero adds the pending radiance if the flag is clear.  Same sums, same bits as unsplit.
-#define RT_MODE_QUEUE 0   // the iteration's queue (closest-hit: entries [first, n) -- the packet kernel takes the primary rays before)
-#define RT_MODE_RESID 1   // the primary rays the packet kernel handed over (q.resid holds their queue indices)
+#define RT_MODE_QUEUE 0   // the iteration's queue (closest-hit: entries [first, n) -- the primary rays before them walk as packets)
 #define RT_MODE_SPLIT 2   // work items of split any-hit walks (round `round` of the iteration)
+
+// What a traversal block keeps in LDS: the per-lane stacks, one row with the wave iteration at which each lane took its ray
+// (any-hit walks), and the staged analytic primitives.  Set up ONCE per block (stageAnalytic has the block's only
+// barrier): the phases of the fused kernel (k_trace) share it, and a wave moves from one phase to the next on its own.
+struct RtTraceLds {
+    RtStack stk;
+    RtLdsWord *age;
+    RtAnalytic an;
+};
+RT_DEV RtTraceLds rtTraceSetup(const RtSceneDev &sc, const RtQueues &q, uint32_t *lds, int stack_entries) {
+    RtTraceLds t;
+    t.stk = rtMakeStack(lds, q.spill, stack_entries);
+    t.age = (RtLdsWord *)(lds + stack_entries * RT_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
+    t.an = stageAnalytic(sc, lds + (stack_entries + 1) * RT_BLOCK);
+    return t;
+}
 
 // L0: level-0 shadow results are stored, not added (RtQueues::occ0) -- an instance of its own, so that the usual one keeps
 // its registers
 template <bool ANY, int STATS, int MODE, bool L0 = false>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
-RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stack_entries, int round,
+RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, const RtTraceLds &tl, int par, uint32_t first, int round,
                        uint32_t budget) {
-    if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(par, round)] == 0) return;  // the usual case: nothing was split
     constexpr bool COUNT = STATS >= 1, PROF = STATS >= 2;
-    extern __shared__ uint32_t s_lds[];
-    const RtStack stk = rtMakeStack(s_lds, q.spill, stack_entries);
-    // one LDS row behind the stack: the wave iteration at which the lane took its ray
-    RtLdsWord *const age = (RtLdsWord *)(s_lds + stack_entries * RT_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
-    const RtAnalytic an = stageAnalytic(sc, s_lds + (stack_entries + 1) * RT_BLOCK);
+    const RtStack &stk = tl.stk;
+    RtLdsWord *const age = tl.age;  // one LDS row behind the stack: the wave iteration at which the lane took its ray
+    const RtAnalytic &an = tl.an;
     const int buf = par;
-    constexpr bool INDIRECT = MODE == RT_MODE_RESID, SPLIT = MODE == RT_MODE_SPLIT;
+    constexpr bool SPLIT = MODE == RT_MODE_SPLIT;
     constexpr uint32_t batch = ANY ? RT_FETCH_BATCH_ANY : RT_FETCH_BATCH_CLOSEST;
     static_assert(ANY || !SPLIT, "only any-hit walks are split");
-    static_assert(!ANY || !INDIRECT, "only primary rays go through the packet kernel");
     const uint32_t n = SPLIT ? min(q.counters[RT_CNT_SPLIT(par, round)], q.split_cap)
-                     : INDIRECT ? q.counters[RT_CNT_RESID(par)]
-                                : (ANY ? min(q.counters[RT_CNT_SHADOW(par)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap));
-    uint32_t *work = q.counters + (SPLIT ? RT_CNT_SPLIT(par, round) + 1 : RT_CNT_WORK_RESID(par));
+                             : (ANY ? min(q.counters[RT_CNT_SHADOW(par)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap));
+    uint32_t *work = q.counters + RT_CNT_SPLIT(par, round) + 1;  // (split rounds: one cursor)
     // The queue is cut into RT_WORK_PARTS contiguous parts with a cursor each (on its own 128-byte line): one
     // cursor for the whole chip saturates -- a returning atomic on one address retires every ~10 ns.  A wave starts
     // in the part of its XCD (workgroups go round-robin over the 8 XCDs) and moves on when a part is used up.
@@ -559,7 +569,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
         }
         if (COUNT && ANY && add) unocc++;
         if (ANY && add && l0store && (smp & RT_SHADOW_L0)) {  // (level-0 hits of this iteration: ring samples from prim_sample0)
-            const size_t at = (size_t)lightw * q.l0_stride + ((smp & q.sample_mask) - q.prim_sample0);
+            const size_t at = (size_t)lightw * q.l0_stride + ((smp & q.sample_mask) - q.l0_sample0);
             q.col0[at] = C;
             q.occ0[at] = 1;
         } else if (ANY && add) {  // (summing runs of equal samples first, as k_shade does, finds too few runs here to pay)
@@ -666,11 +676,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     // even entries first, then the odd ones (order is free: results go to the ray's own slot): 39 -> 42 of
                     // 64 lanes per node phase, k_closest 179 -> 161 ms on the 4K frame.  (Unpaired rays shift the parity;
                     // that only weakens the separation.)
-                    if (!ANY && !INDIRECT) {
+                    if (!ANY) {
                         const uint32_t off = pos - pool_base, len = pool_end - pool_base, half = (len + 1u) >> 1;
                         pos = pool_base + (off < half ? 2u * off : 2u * (off - half) + 1u);
                     }
-                    ray_i = INDIRECT ? q.resid[pos] : pos;
+                    ray_i = pos;
                 }
                 if (!nothing) A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
                 if (ANY && !nothing) light = q.shL[ray_i];
@@ -836,8 +846,9 @@ typedef uint32_t u16v __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) u16v *RtScalarRecs;  // constant address space: uniform loads become s_load
 
 template <bool STATS>
-RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t root_ref, const RtQueues &q, int par,
+RT_DEV void tracePacket(const RtSceneDev &sc, const RtTraceLds &tl, uint32_t root_ref, const RtQueues &q, int par,
                         uint32_t pb, uint32_t n, unsigned long long *prof) {
+    const RtAnalytic &an = tl.an;
     const uint32_t lane = laneId();
     const int buf = par;
     const uint32_t i = pb + lane;
@@ -961,33 +972,42 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtAnalytic &an, uint32_t roo
             }
         }
     }
-    if (toResid) {  // hand the packet's live rays to the per-lane kernel (which starts them from scratch)
-        const bool go = valid && !(sample & RT_FLAG_INVALID);
-        const unsigned long long gm = __ballot(go);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(q.counters + RT_CNT_RESID(par), (uint32_t)__popcll(gm));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (go) q.resid[base + maskRankBelow(gm)] = i;
-        if (STATS) prof[7] += (unsigned long long)__popcll(gm);
-        if (valid && !go) q.hits[i] = make_float2(INFINITY, __uint_as_float(RT_ID_MISS));
-        return;
+    if (toResid) {
+        // Incoherent packet: its rays finish as per-lane walks right here, from the root, with the best hit found so far
+        // (re-testing a triangle gives the same distance, and the tie rule never replaces a hit by itself).  A few per
+        // cent of the packets; handing them to a follow-up launch cost a launch tail per iteration.
+        if (STATS) prof[7] += (unsigned long long)__popcll(am);
+        bool has = alive;
+        w.cur = has ? root_ref : RT_NODE_DONE;
+        w.pend = RT_NODE_DONE;
+        w.sp = 0;
+        RtTraversalStats st{0, 0};
+        while (__ballot(has)) {
+            if (has) rtPostponeLeaf(w, tl.stk);
+            const bool atNode = has && !(w.cur & RT_NODE_LEAF), atTri = has && w.pend != RT_NODE_DONE;
+            const int nNode = (int)__popcll(__ballot(atNode)), nTri = (int)__popcll(__ballot(atTri));
+            if (nNode >= nTri && nNode > 0) {
+                if (atNode) rtNodeStep<false, false>(sc, w, tl.stk, st);
+            } else if (nTri > 0) {
+                if (atTri) rtTriStep<false, false>(sc, w, st);
+            }
+            if (has && w.cur == RT_NODE_DONE && w.pend == RT_NODE_DONE) has = false;
+        }
     }
     if (valid) q.hits[i] = make_float2(w.best_t, __uint_as_float(w.best_id));
 }
 
-// the primary rays of the iteration: entries [0, q.prim_n) of ray queue `par`
+// the primary rays of the entering chunk: entries [0, q.prim_n) of ray queue `par`, 64 at a time
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par) {
-    extern __shared__ uint32_t s_lds[];
-    const RtAnalytic an = stageAnalytic(sc, s_lds);
+RT_DEV void packetQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, const RtTraceLds &tl, int par) {
     const uint32_t n = min(q.prim_n, q.ray_cap);
     uint32_t *work = q.counters + RT_CNT_PWORK(par);
     // STATS: [0] packets, [1] node steps, [2] lanes interested in a child per node step, [3] triangle steps, [4] live
-    // lanes per triangle step, [5] packets over budget, [6] octant groups walked, [7] rays handed to the lane kernel
+    // lanes per triangle step, [5] packets over budget, [6] octant groups walked, [7] rays that finished as per-lane walks
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // Guided batches: a wave walks the packets of its batch one after the other (~0.15 ms each), so the last batches of a
-    // launch keep a few waves busy for RT_PACKET_BATCH packets while the chip idles (1.4 ms per launch).  Towards the end
-    // of the queue a wave takes fewer packets per fetch; how far the queue has got is known from its previous fetch.
+    // Guided batches: a wave walks the packets of its batch one after the other, so the last batches of a launch keep a
+    // few waves busy for RT_PACKET_BATCH packets while the chip idles.  Towards the end of the queue a wave takes fewer
+    // packets per fetch; how far the queue has got is known from its previous fetch.
     const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64);
     uint32_t seen = 0;
     for (;;) {
@@ -1001,7 +1021,7 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t 
         const uint32_t end = min(base + want, n);
         for (uint32_t pb = base; pb < end; pb += 64u) {
             if (STATS) prof[0]++;
-            tracePacket<STATS>(sc, an, root_ref, q, par, pb, n, prof);
+            tracePacket<STATS>(sc, tl, root_ref, q, par, pb, n, prof);
         }
     }
     if (STATS && laneId() == 0) {
@@ -1010,14 +1030,44 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t 
     }
 }
 
-template <int STATS, int MODE>
+// The traversal kernels.  All of them use the same LDS layout (RtTraceLds) and 64 VGPRs (8 waves per SIMD).
+// k_trace is the FUSED form the frame loop launches once per iteration: its waves work off, one phase after the other
+// and each wave at its own pace, (1) the shadow queue of iteration j, (2) the bounce rays of iteration j + 1 (appended by
+// k_shade(j), which ran before this launch), (3) the primary rays of the chunk that enters at j + 1, as packets.  The
+// three are independent of each other, and a persistent launch ends with its longest walk: separate launches paid
+// that tail three times per iteration (~0.3 ms each), here the tails of (1) and (2) are filled by the next phase.
+// par_any / par_closest < 0: the phase has no work (first and last iterations).
+template <int STATS, bool L0>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_trace(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par_any, int par_closest, uint32_t first,
+                                                       int packets, int stack_entries, uint32_t budget) {
+    extern __shared__ uint32_t s_lds[];
+    const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
+    if (par_any >= 0) traceQueue<true, STATS, RT_MODE_QUEUE, L0>(sc, root_ref, q, tl, par_any, 0u, -1, budget);
+    if (par_closest >= 0) {
+        traceQueue<false, STATS, RT_MODE_QUEUE>(sc, root_ref, q, tl, par_closest, first, -1, 0u);
+        if (packets) packetQueue<(STATS != 0)>(sc, root_ref, q, tl, par_closest);
+    }
+}
+// the phases as launches of their own (per-kernel timing: collect_stats & 2, RT_FUSE=0; rt_trace_batch; the split rounds)
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries) {
+    extern __shared__ uint32_t s_lds[];
+    const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
+    packetQueue<STATS>(sc, root_ref, q, tl, par);
+}
+template <int STATS>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, uint32_t first, int stack_entries) {
-    traceQueue<false, STATS, MODE>(sc, root_ref, q, par, first, stack_entries, -1, 0u);
+    extern __shared__ uint32_t s_lds[];
+    const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
+    traceQueue<false, STATS, RT_MODE_QUEUE>(sc, root_ref, q, tl, par, first, -1, 0u);
 }
 template <int STATS, int MODE, bool L0 = false>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries, int round,
                                                      uint32_t budget) {
-    traceQueue<true, STATS, MODE, L0>(sc, root_ref, q, par, 0u, stack_entries, round, budget);
+    if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(par, round)] == 0) return;  // the usual case: nothing was split
+    extern __shared__ uint32_t s_lds[];
+    const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
+    traceQueue<true, STATS, MODE, L0>(sc, root_ref, q, tl, par, 0u, round, budget);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1071,10 +1121,13 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     const int buf = par, nbuf = par ^ 1;
     const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(par)], q.ray_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap);
     // A wave shades SEGMENTS of consecutive queue entries (consecutive entries are neighbouring samples / hits), so the
-    // rays it appends to a slab leave neighbouring points towards one light.  Segments are dealt round-robin to the
-    // waves; their length adapts to the queue so that every wave still gets several.
-    const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64), gwave = blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6);
+    // rays it appends to a slab leave neighbouring points towards one light.  A wave takes its next segment from a
+    // cursor (one atomic per segment): segments cost very differently (misses are only scanned), and dealing them out
+    // in fixed order left the launch waiting for the waves that drew the expensive ones.  Their length adapts to the
+    // queue so that every wave still gets several.
+    const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64);
     const uint32_t seg = min(max((n / (nwaves * 8u)) & ~63u, 64u), RT_SHADE_SEGMENT);
+    uint32_t *const segCursor = q.counters + (GENERAL ? RT_CNT_WORK_SHADEG(par) : RT_CNT_WORK_SHADE(par));
     const uint32_t lane = laneId();
     const int nlights = sc.n_lights;
     uint32_t culled = 0, shaded = 0, zero = 0, l0lit = 0;
@@ -1089,9 +1142,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     // sample whose ray missed (see below).  Order is kept, so sibling pairs and runs of equal samples stay neighbours.
     __shared__ uint32_t s_ring[RT_BLOCK / 64][128];
     uint32_t *const ring = s_ring[threadIdx.x >> 6];
-    uint64_t seg0 = (uint64_t)gwave * seg;           // wave-uniform scan state
+    uint32_t seg0 = waveReserve(segCursor, seg);     // wave-uniform scan state (the cursor runs past n by at most one segment per wave)
     bool moreSeg = seg0 < n;
-    uint32_t scan = (uint32_t)seg0, segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n), head = 0, count = 0;
+    uint32_t scan = seg0, segEnd = min(seg0 + seg, n), head = 0, count = 0;
     while (moreSeg || count) {
         while (count < 64 && moreSeg) {
             const uint32_t j = scan + lane;
@@ -1133,10 +1186,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             count += (uint32_t)__popcll(hm);
             scan += 64;
             if (scan >= segEnd) {  // next segment of this wave
-                seg0 += (uint64_t)nwaves * seg;
+                seg0 = waveReserve(segCursor, seg);
                 moreSeg = seg0 < n;
-                scan = (uint32_t)seg0;
-                segEnd = (uint32_t)min(seg0 + seg, (uint64_t)n);
+                scan = seg0;
+                segEnd = min(seg0 + seg, n);
             }
         }
         RT_PROF_MARK(2)
@@ -1491,9 +1544,9 @@ __global__ void k_iter_ctl(RtQueues q, int prev, uint32_t prim_next, int set_cur
     c[RT_CNT_RAYS(prev)] = prim_next;
     c[RT_CNT_SHADOW(prev)] = 0;
     c[RT_CNT_GENERAL(prev)] = 0;
-    c[RT_CNT_RESID(prev)] = 0;
+    c[RT_CNT_WORK_SHADE(prev)] = 0;
     c[RT_CNT_PWORK(prev)] = 0;
-    c[RT_CNT_WORK_RESID(prev)] = 0;
+    c[RT_CNT_WORK_SHADEG(prev)] = 0;
     for (int k = 0; k < RT_WORK_PARTS; k++) {
         c[RT_CNT_WORKP_CLOSEST(prev, k)] = 0;
         c[RT_CNT_WORKP_ANY(prev, k)] = 0;
@@ -1654,49 +1707,64 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 // (stats: 0 = plain, 1 = counters, 2 = counters + wave-time profile)
 #define RT_BY_STATS(CALL) do { if (stats >= 2) { CALL(2); } else if (stats == 1) { CALL(1); } else { CALL(0); } } while (0)
 static inline size_t traceLds(const RtLaunchCfg &cfg) { return (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes; }
-// the iteration's primary rays (entries [0, q.prim_n) of ray queue `par`) as packets
-void rtLaunchPacket(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
-    const dim3 block(RT_BLOCK);
-    if (stats) hipLaunchKernelGGL((k_packet<true>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, par);
-    else hipLaunchKernelGGL((k_packet<false>), dim3(gridFor(cfg, 8)), block, (size_t)cfg.analytic_bytes, cfg.stream, sc, root_ref, q, par);
-}
-// per-lane closest-hit walks: resid = the primary rays the packet kernel handed over, else entries [first, n) of the queue
-void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stats, bool resid) {
+static inline uint32_t splitBudget(const RtLaunchCfg &cfg, const RtQueues &q) { return q.split_cap ? (uint32_t)cfg.split_budget : 0u; }
+// The fused traversal launch of an iteration (k_trace): shadow queue `par_any`, bounce rays [first, n) of ray queue
+// `par_closest`, its primary rays [0, q.prim_n) as packets.  A parity < 0 skips the phase.
+void rtLaunchTrace(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par_any, int par_closest,
+                   uint32_t first, bool packets, int stats) {
     const size_t lds = traceLds(cfg);
     const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
-#define RT_C_RESID(S) hipLaunchKernelGGL((k_closest<S, RT_MODE_RESID>), grid, block, lds, cfg.stream, sc, root_ref, q, par, 0u, cfg.stack_entries)
-#define RT_C_QUEUE(S) hipLaunchKernelGGL((k_closest<S, RT_MODE_QUEUE>), grid, block, lds, cfg.stream, sc, root_ref, q, par, first, cfg.stack_entries)
-    if (resid) RT_BY_STATS(RT_C_RESID); else RT_BY_STATS(RT_C_QUEUE);
-#undef RT_C_RESID
+    const uint32_t budget = splitBudget(cfg, q);
+#define RT_T(S)                                                                                                                                        \
+    do {                                                                                                                                               \
+        if (q.occ0) hipLaunchKernelGGL((k_trace<S, true>), grid, block, lds, cfg.stream, sc, root_ref, q, par_any, par_closest, first, packets ? 1 : 0, cfg.stack_entries, budget);  \
+        else hipLaunchKernelGGL((k_trace<S, false>), grid, block, lds, cfg.stream, sc, root_ref, q, par_any, par_closest, first, packets ? 1 : 0, cfg.stack_entries, budget);       \
+    } while (0)
+    RT_BY_STATS(RT_T);
+#undef RT_T
+}
+// the same phases as launches of their own
+void rtLaunchPacket(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
+    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
+    if (stats) hipLaunchKernelGGL((k_packet<true>), grid, block, traceLds(cfg), cfg.stream, sc, root_ref, q, par, cfg.stack_entries);
+    else hipLaunchKernelGGL((k_packet<false>), grid, block, traceLds(cfg), cfg.stream, sc, root_ref, q, par, cfg.stack_entries);
+}
+void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, uint32_t first, int stats) {
+    const size_t lds = traceLds(cfg);
+    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
+#define RT_C_QUEUE(S) hipLaunchKernelGGL((k_closest<S>), grid, block, lds, cfg.stream, sc, root_ref, q, par, first, cfg.stack_entries)
+    RT_BY_STATS(RT_C_QUEUE);
 #undef RT_C_QUEUE
 }
-// the iteration's shadow queue, then the follow-up rounds over the work items of split walks
-void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
-    const size_t lds = traceLds(cfg);
-    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
-    const uint32_t budget = q.split_cap ? (uint32_t)cfg.split_budget : 0u;
 #define RT_LAUNCHA(S, M, G, R, B)                                                                                                     \
     do {                                                                                                                              \
         if (q.occ0) hipLaunchKernelGGL((k_any<S, M, true>), G, block, lds, cfg.stream, sc, root_ref, q, par, cfg.stack_entries, R, B);  \
         else hipLaunchKernelGGL((k_any<S, M, false>), G, block, lds, cfg.stream, sc, root_ref, q, par, cfg.stack_entries, R, B);       \
     } while (0)
+void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
+    const size_t lds = traceLds(cfg);
+    const dim3 grid(gridFor(cfg, cfg.trace_blocks_per_cu)), block(RT_BLOCK);
+    const uint32_t budget = splitBudget(cfg, q);
 #define RT_A_QUEUE(S) RT_LAUNCHA(S, RT_MODE_QUEUE, grid, -1, budget)
     RT_BY_STATS(RT_A_QUEUE);
 #undef RT_A_QUEUE
-    if (budget) {
-        // follow-up rounds (almost always without work: their waves read a zero count and leave); a quarter of the grid is
-        // plenty, the last round walks whatever is left to the end
-        const dim3 sgrid(gridFor(cfg, cfg.trace_blocks_per_cu >= 4 ? cfg.trace_blocks_per_cu / 4 : 1));
-        for (int r = 0; r < RT_SPLIT_ROUNDS; r++) {
-            // items get an eighth of the budget: a round then lasts ~0.15 ms and the items multiply faster
-            const uint32_t b = r == RT_SPLIT_ROUNDS - 1 ? 0u : (budget >= 64u ? budget / 8u : budget);
-#define RT_A_SPLIT(S) RT_LAUNCHA(S, RT_MODE_SPLIT, sgrid, r, b)
-            RT_BY_STATS(RT_A_SPLIT);
-#undef RT_A_SPLIT
-        }
-    }
-#undef RT_LAUNCHA
 }
+// follow-up rounds over the work items of split shadow walks of queue `par` (almost always without work: their waves read
+// a zero count and leave); a quarter of the grid is plenty, the last round walks whatever is left to the end
+void rtLaunchSplitRounds(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats) {
+    const uint32_t budget = splitBudget(cfg, q);
+    if (!budget) return;
+    const size_t lds = traceLds(cfg);
+    const dim3 block(RT_BLOCK), sgrid(gridFor(cfg, cfg.trace_blocks_per_cu >= 4 ? cfg.trace_blocks_per_cu / 4 : 1));
+    for (int r = 0; r < RT_SPLIT_ROUNDS; r++) {
+        // items get an eighth of the budget: a round then lasts ~0.15 ms and the items multiply faster
+        const uint32_t b = r == RT_SPLIT_ROUNDS - 1 ? 0u : (budget >= 64u ? budget / 8u : budget);
+#define RT_A_SPLIT(S) RT_LAUNCHA(S, RT_MODE_SPLIT, sgrid, r, b)
+        RT_BY_STATS(RT_A_SPLIT);
+#undef RT_A_SPLIT
+    }
+}
+#undef RT_LAUNCHA
 #undef RT_BY_STATS
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int par, int max_depth, int spp,
                    uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs) {

@@ -189,13 +189,14 @@ struct RtQueues {
     long long *accum;          // [ring samples][3] fixed point
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
-    uint32_t *resid;           // rays the packet kernels hand to the per-lane kernels (queue indices)
     uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap;
     // this iteration (set by the host per launch): entries [0, prim_n) of the current ray queue are the primary rays of the
     // chunk that enters the pipeline -- level 0, entry k belongs to ring sample prim_sample0 + k
     uint32_t prim_n, prim_sample0;
+    uint32_t l0_sample0;       // ring sample of the first level-0 shadow ray's chunk (the fused k_trace walks the shadow rays of
+                               // iteration j next to the primary rays of chunk j + 1, which prim_n / prim_sample0 then describe)
     uint32_t sample_mask;      // tag & sample_mask = ring sample
     uint32_t level_shift, level_mask;  // (tag >> level_shift) & level_mask = level of the ray
     // Level-0 shadow results without atomics (null = off): a sample has ONE level-0 hit, hence at most one level-0 shadow
@@ -228,9 +229,9 @@ struct RtQueues {
 #define RT_CNT_UNOCCLUDED (14 * RT_CNT_STRIDE + 4)           // u64: shadow rays that reached their light (stats build)
 #define RT_CNT_SHADOW_L0 (14 * RT_CNT_STRIDE + 12)           // shadow rays emitted by level-0 hits (decides RtQueues::occ0)
 #define RT_CNT_GENERAL(p) ((15 + (p)) * RT_CNT_STRIDE)       // hits of iteration parity p left to the general k_shade
-#define RT_CNT_RESID(p) ((17 + (p)) * RT_CNT_STRIDE)         // primary rays the packet kernel handed to the per-lane closest-hit kernel
+#define RT_CNT_WORK_SHADE(p) ((17 + (p)) * RT_CNT_STRIDE)    // next unclaimed segment of ray queue p (fast k_shade)
 #define RT_CNT_PWORK(p) ((19 + (p)) * RT_CNT_STRIDE)         // next unclaimed packet batch (packet kernel)
-#define RT_CNT_WORK_RESID(p) ((21 + (p)) * RT_CNT_STRIDE)    // next unclaimed entry of the hand-over list
+#define RT_CNT_WORK_SHADEG(p) ((21 + (p)) * RT_CNT_STRIDE)   // next unclaimed segment of the general list (general k_shade)
 // Frame totals (u64 each, one line): k_iter_ctl moves the per-iteration 32-bit counters here after every iteration, so
 // that no 32-bit counter has to hold more than one iteration's worth
 #define RT_CNT_TOTALS (23 * RT_CNT_STRIDE)
