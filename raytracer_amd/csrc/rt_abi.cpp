@@ -69,6 +69,10 @@ struct DevBuf {
 struct rt_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    // a frame's second pipeline runs on a stream of its own, forked from and joined to the caller's stream by these events
+    // (created at rt_create: the render entry points create no stream or event)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     RtLaunchCfg cfg;
     // host-side scene as handed over through rt_set_*
     std::vector<rt_material> materials;
@@ -91,7 +95,8 @@ struct rt_context {
     RtBvh bvh;
     std::vector<int64_t> mesh_first;  // per object: first global triangle index (or -1)
     DevBuf<RtNode4> d_records;  // BVH nodes, then the triangle records (rt_types.h)
-    DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part
+    DevBuf<uint32_t> d_spill;   // traversal stack entries beyond the LDS part: one area of spill_words per lane of a frame (rt_frame.inl)
+    size_t spill_words = 0;
     DevBuf<RtNodeP> d_nodes_p;  // float-box form of the nodes (packet kernels)
     DevBuf<RtTriShade> d_shade;
     DevBuf<RtSphere> d_spheres;
@@ -102,7 +107,7 @@ struct rt_context {
     DevBuf<uint8_t> d_bmp[4];
     RtSceneDev dev{};
     // Wavefront workspace: ONE arena, carved anew for every frame (carveQueues).  It is allocated once -- the whole budget
-    // (RT_WORKSPACE_GB, 24 GiB by default) for a frame that needs more than one chunk, what the frame needs otherwise -- and
+    // (RT_WORKSPACE_GB, 30 GiB by default) for a frame that needs more than one chunk, what the frame needs otherwise -- and
     // grows only when a later call cannot fit a single tile into it or asks for a chunk size of its own.
     DevBuf<unsigned char> d_arena;
     // Fan-out observed on this scene since rt_commit: queue entries per primary sample of a chunk that one iteration of the
@@ -151,9 +156,16 @@ int rt_create(int device_id, rt_context **out) {
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
     ctx->cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
         delete ctx;
-        return fail("rt_create: hipStreamCreate failed");
+        return fail("rt_create: hipStreamCreate / hipEventCreate failed");
     }
     {   // address of the static scratch on THIS device (looked up once per device, with that device current)
         static std::mutex mu;
@@ -190,6 +202,9 @@ int rt_destroy(rt_context *ctx) {
     for (int k = 0; k < 4; k++) ctx->d_bmp[k].release();
     ctx->d_t8.release(); ctx->d_o8.release(); ctx->d_tf.release(); ctx->d_of.release(); ctx->d_tp.release(); ctx->d_op.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
     return 0;
 }
@@ -510,7 +525,8 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
     if (const char *e = getenv("RT_TRACE_BLOCKS")) ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(ctx->cfg.trace_blocks_per_cu, atoi(e)));  // (tuning knob)
     const size_t spill_entries = (size_t)std::max(0, src->bvh.max_stack - entries);
-    if (ctx->d_spill.alloc(std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256))) return 1;
+    ctx->spill_words = std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256);
+    if (ctx->d_spill.alloc(2 * ctx->spill_words)) return 1;
     HIPOK(hipDeviceSynchronize());
     ctx->commit_stats.ms_upload = nowMs() - t0;
     ctx->committed = true;

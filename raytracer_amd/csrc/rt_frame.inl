@@ -53,6 +53,7 @@ struct CarveSpec {
     size_t samples = 0;    // primary samples per chunk
     int ring = 1;          // chunks in flight = slots of the accumulator ring
     size_t ray_cap = 0, sh_cap = 0, split_cap = 0;
+    size_t general_cap = 0;  // entries of the list of hits for the general k_shade (0 for scenes without such primitives)
     int nl = 1;
     bool l0 = false;       // level-0 shadow results stored, not added (RtQueues::occ0)
     int max_depth = 0;
@@ -77,7 +78,8 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     q.shC = (float4 *)take(c.sh_cap * sizeof(float4));
     q.shL = (uint8_t *)take(c.sh_cap);
     q.accum = (long long *)take((size_t)c.ring * c.samples * 3 * sizeof(long long));
-    q.general = (uint32_t *)take(c.ray_cap * sizeof(uint32_t));
+    q.general = (uint32_t *)take(c.general_cap * sizeof(uint32_t));
+    q.general_cap = (uint32_t)c.general_cap;
     if (c.l0) {
         q.occ0 = (uint8_t *)take(c.samples * (size_t)c.nl);
         q.col0 = (float4 *)take(c.samples * (size_t)c.nl * sizeof(float4));
@@ -91,13 +93,15 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     q.level_shift = (uint32_t)(30 - bits);
     q.level_mask = (1u << bits) - 1u;
     q.sample_mask = (1u << q.level_shift) - 1u;
+    q.tile_stride = 1;  // (set per frame: enqueueFrame)
     return off;
 }
 
 // How a frame of `n_local` tiles is cut into chunks and what its queues hold.
 struct FramePlan {
     size_t tiles = 0, samples = 0, nchunks = 0;  // tiles / primary sample slots per chunk; chunks of the frame
-    int ring = 1;                                // chunks in flight (min(nchunks, depth + 1))
+    int lanes = 1;                               // independent pipelines (chunk c runs in lane c % lanes), each on a stream of its own
+    int ring = 1;                                // chunks in flight per lane (min(chunks of a lane, depth + 1))
     bool optimistic = false;                     // queues sized from the fan-out observed on the scene, not for the worst case
     double ray_fan = 0.0, sh_fan = 0.0;
     QueueSizes z;
@@ -111,8 +115,9 @@ struct PlanInput {
     bool worst = false;         // size for the worst case even where a fan-out has been observed
     bool l0 = false;
     size_t split_cap = 0;
-    double margin = 1.5;
+    double margin = 1.25;       // queue capacity over the fullest queue seen on the scene so far
     size_t budget = 0;          // bytes the workspace may take (ignored for a caller-given chunk size)
+    int lanes = 1;              // pipelines to run side by side where the frame has at least that many chunks
 };
 // The fewest (hence largest, and equal) chunks whose workspace fits the budget.  Returns false if not even one tile per
 // chunk fits.
@@ -124,7 +129,8 @@ bool planFrame(const rt_context *ctx, const RtLaunchCfg &cfg, const PlanInput &i
         o = FramePlan{};
         o.tiles = tiles;
         o.nchunks = (in.n_local + tiles - 1) / tiles;
-        o.ring = (int)std::min<size_t>(o.nchunks, (size_t)D + 1);
+        o.lanes = (int)std::min<size_t>((size_t)std::max(in.lanes, 1), o.nchunks);
+        o.ring = (int)std::min<size_t>((o.nchunks + o.lanes - 1) / o.lanes, (size_t)D + 1);
         o.samples = tiles * in.per_tile;
         o.optimistic = optimistic;
         const double wf = worstFan(D, (size_t)o.ring);
@@ -136,12 +142,13 @@ bool planFrame(const rt_context *ctx, const RtLaunchCfg &cfg, const PlanInput &i
         o.spec.ring = o.ring;
         o.spec.ray_cap = o.z.ray_cap;
         o.spec.sh_cap = o.z.sh_cap;
+        o.spec.general_cap = ctx->dev.has_general ? o.z.ray_cap : 64;  // (dev: what rt_commit put on THIS device, also in a replica of rt_multi)
         o.spec.split_cap = in.split_cap;
         o.spec.nl = in.nl;
         o.spec.l0 = in.l0;
         o.spec.max_depth = D;
         RtQueues dummy;
-        o.bytes = carveQueues(nullptr, o.spec, nullptr, dummy);
+        o.bytes = (size_t)o.lanes * carveQueues(nullptr, o.spec, nullptr, dummy);
         return true;
     };
     if (in.n_local == 0) return eval(1, pl);
@@ -153,9 +160,11 @@ bool planFrame(const rt_context *ctx, const RtLaunchCfg &cfg, const PlanInput &i
     }
     size_t prev = 0;
     for (size_t nc = 1; nc <= in.n_local; nc++) {
-        const size_t tiles = (in.n_local + nc - 1) / nc;
+        size_t tiles = (in.n_local + nc - 1) / nc;
         if (tiles == prev) continue;
         prev = tiles;
+        // (lanes that get the same number of chunks finish together: skip counts that would not divide, where that is possible)
+        if (in.lanes > 1 && nc > 1 && ((in.n_local + tiles - 1) / tiles) % (size_t)in.lanes != 0 && tiles > 1) continue;
         if (eval(tiles, pl) && pl.bytes <= in.budget) return true;
         if (tiles == 1) break;
     }
@@ -236,45 +245,93 @@ void addCounters(rt_stats *st, const uint32_t *c) {
     for (int k = 0; k < 8; k++) st->prof_packet_closest[k] += u64at(RT_CNT_PROF_PACKET + 2 * k);  // (prof_packet_any: no shadow packets)
 }
 
-// Enqueues a whole frame on cfg.stream: no host synchronisation, no allocation.  Launch order (S = k_shade, A = shadow
+// RT_TAILPROF=1 (diagnosis): the launches of a frame record when their waves start and end (RtQueues::tailprof)
+struct TailProf {
+    DevBuf<unsigned long long> buf;
+    struct Rec { int cls; uint32_t waves; };
+    std::vector<Rec> recs;
+    bool on = false;
+    uint32_t next(int cls, uint32_t waves) {
+        recs.push_back(Rec{cls, waves});
+        return (uint32_t)recs.size() - 1;
+    }
+};
+
+// Enqueues a whole frame: no host synchronisation, no allocation.  Launch order of a pipeline (S = k_shade, A = shadow
 // rays, C = bounce rays, P = primary packets, the index is the iteration = the ray queue):
 //     ctl(0) gen(0) [C|P](0)   then per iteration j:   ctl(j) S(j) gen(j+1) [A(j)|C(j+1)|P(j+1)] splits(j) fold0(j) resolve(j-D)
 // A(j), C(j+1) and P(j+1) only depend on S(j) / gen(j+1), so they share ONE persistent launch (k_trace) whose waves go
 // from one to the next at their own pace.  `fuse` = false launches them one after the other (per-kernel timing, RT_FUSE=0).
-int enqueueFrame(rt_context *ctx, const RtLaunchCfg &cfg, const RtFrameDev &f, const FramePlan &pl, const RtQueues &q0, int max_depth,
+// What is left is a chain -- S(j) needs the hits of k_trace(j-1), which needs the rays of S(j-1) -- and every link ends
+// with its slowest wave (~0.3 ms of a mostly idle chip per launch).  So a frame of several chunks runs as pl.lanes
+// INDEPENDENT pipelines (chunk c in lane c % lanes, each lane with queues and counters of its own: q0[lane]) on streams
+// of their own: every kernel fetches its work dynamically, so the blocks of one lane's launch fill the CUs that the
+// other lane's launch leaves idle at its end.  Lane 0 runs on cfg.stream, lane 1 on ctx->stream2, forked from and joined
+// to cfg.stream by events.
+int enqueueFrame(rt_context *ctx, const RtLaunchCfg &cfg0, const RtFrameDev &f, const FramePlan &pl, const RtQueues *q0, int max_depth,
                  size_t n_local, size_t per_tile, uint8_t *d_rgb8, float *d_rgbf, uint32_t *d_primid, int stats, bool fuse, KernelTimer &kt,
-                 rt_stats *st) {
-    hipStream_t stream = cfg.stream;
+                 rt_stats *st, TailProf *tp = nullptr) {
+    const int lanes = pl.lanes;
+    auto probe = [&](RtQueues &q, int cls, uint32_t waves) {
+        if (!tp || !tp->on) return;
+        q.tailprof = tp->buf.p;
+        q.launch_id = tp->next(cls, waves);
+    };
+    if (lanes > 2) return fail("enqueueFrame: at most two lanes");
+    hipStream_t streams[2] = {cfg0.stream, ctx->stream2};
     // the workspace keeps the last frame's contents: counters, work cursors and totals start at zero; queues and sample
     // accumulators are written before they are read (level-0 k_shade stores every sample slot of a chunk)
-    HIPOK(hipMemsetAsync(q0.counters, 0, RT_CNT_WORDS * sizeof(uint32_t), stream));
-    if (q0.occ0) HIPOK(hipMemsetAsync(q0.occ0, 0, pl.samples * (size_t)pl.spec.nl, stream));  // (k_fold0 clears what it folds)
-    if (d_primid && n_local) HIPOK(hipMemsetAsync(d_primid, 0xFF, n_local * RT_TILE_PIXELS * sizeof(uint32_t), stream));
+    for (int l = 0; l < lanes; l++) {
+        HIPOK(hipMemsetAsync(q0[l].counters, 0, RT_CNT_WORDS * sizeof(uint32_t), streams[0]));
+        if (q0[l].occ0) HIPOK(hipMemsetAsync(q0[l].occ0, 0, pl.samples * (size_t)pl.spec.nl, streams[0]));  // (k_fold0 clears what it folds)
+    }
+    if (d_primid && n_local) HIPOK(hipMemsetAsync(d_primid, 0xFF, n_local * RT_TILE_PIXELS * sizeof(uint32_t), streams[0]));
     if (n_local == 0) return 0;
-    const size_t nchunks = pl.nchunks, T = nchunks + (size_t)max_depth;
+    if (lanes > 1) {
+        HIPOK(hipEventRecord(ctx->ev_fork, streams[0]));
+        HIPOK(hipStreamWaitEvent(streams[1], ctx->ev_fork, 0));
+    }
+    const size_t nchunks = pl.nchunks;
     const uint32_t root = ctx->bvh.root_ref;
     const int nlights = (int)ctx->lights.size();
-    auto ntilesOf = [&](size_t c) { return (uint32_t)std::min(pl.tiles, n_local - c * pl.tiles); };
-    auto primN = [&](size_t j) { return j < nchunks ? ntilesOf(j) * (uint32_t)per_tile : 0u; };
-    auto sample0 = [&](size_t c) { return (uint32_t)((c % (size_t)pl.ring) * pl.samples); };
     const uint64_t max_inputs = (uint64_t)std::ceil((double)pl.samples * pl.ray_fan);
+    // chunk c = local tiles c, c + nchunks, c + 2 nchunks, ...: every chunk a sample of the whole image (rt_kernels.hip)
+    auto ntilesOf = [&](size_t c) { return (uint32_t)((n_local - c + nchunks - 1) / nchunks); };
+    // lane-local view: iteration j of lane l brings in chunk c = l + j * lanes
+    struct Lane { size_t nk, T; RtLaunchCfg cfg; };
+    Lane L[2];
+    size_t Tmax = 0;
+    for (int l = 0; l < lanes; l++) {
+        L[l].nk = (nchunks - (size_t)l + (size_t)lanes - 1) / (size_t)lanes;
+        L[l].T = L[l].nk + (size_t)max_depth;
+        L[l].cfg = cfg0;
+        L[l].cfg.stream = streams[l];
+        Tmax = std::max(Tmax, L[l].T);
+    }
+    auto chunkOf = [&](int l, size_t j) { return (size_t)l + j * (size_t)lanes; };
+    auto primN = [&](int l, size_t j) { return j < L[l].nk ? ntilesOf(chunkOf(l, j)) * (uint32_t)per_tile : 0u; };
+    auto sample0 = [&](size_t j) { return (uint32_t)((j % (size_t)pl.ring) * pl.samples); };
     // queue j's primary rays (if a chunk enters at j) and closest hits: everything k_shade(j) will read
-    auto enter = [&](size_t j, int par_any) {  // par_any: the shadow queue walked next to it (-1: none)
-        RtQueues q = q0;
-        q.prim_n = primN(j);
-        q.prim_sample0 = j < nchunks ? sample0(j) : 0u;
-        q.l0_sample0 = j >= 1 && j - 1 < nchunks ? sample0(j - 1) : 0u;  // (the shadow rays are those of iteration j - 1)
+    auto enter = [&](int l, size_t j, int par_any) {  // par_any: the shadow queue walked next to it (-1: none)
+        const RtLaunchCfg &cfg = L[l].cfg;
+        kt.stream = cfg.stream;
+        RtQueues q = q0[l];
+        q.tile_stride = (uint32_t)nchunks;
+        q.prim_n = primN(l, j);
+        q.prim_sample0 = j < L[l].nk ? sample0(j) : 0u;
+        q.l0_sample0 = j >= 1 && j - 1 < L[l].nk ? sample0(j - 1) : 0u;  // (the shadow rays are those of iteration j - 1)
         const int par = (int)(j & 1);
         if (q.prim_n) {
             kt.begin(0);
-            rtLaunchGenPrimary(cfg, f, q, par, (uint32_t)(j * pl.tiles), ntilesOf(j));
+            rtLaunchGenPrimary(cfg, f, q, par, (uint32_t)chunkOf(l, j), ntilesOf(chunkOf(l, j)));
             kt.end();
         }
-        const bool pk = cfg.packets && q.prim_n > 0, queue_j = j < T;
+        const bool pk = cfg.packets && q.prim_n > 0, queue_j = j < L[l].T;
         const uint32_t first = pk ? q.prim_n : 0u;
         if (fuse) {
             if (par_any < 0 && !queue_j) return;
             kt.begin(6);
+            probe(q, 6, (uint32_t)(cfg.num_cus * cfg.trace_blocks_per_cu * 4));
             rtLaunchTrace(cfg, ctx->dev, root, q, par_any, queue_j ? par : -1, first, pk, stats);
             kt.end();
         } else {
@@ -299,31 +356,48 @@ int enqueueFrame(rt_context *ctx, const RtLaunchCfg &cfg, const RtFrameDev &f, c
             if (par_any >= 0) st->launches_any++;
         }
     };
-    rtLaunchIterCtl(cfg, q0, 1, primN(1), true, primN(0));
-    enter(0, -1);
-    for (size_t j = 0; j < T; j++) {
-        const int par = (int)(j & 1);
-        RtQueues q = q0;
-        q.prim_n = primN(j);
-        q.prim_sample0 = j < nchunks ? sample0(j) : 0u;
-        q.l0_sample0 = q.prim_sample0;
-        if (j > 0) rtLaunchIterCtl(cfg, q, par ^ 1, primN(j + 1), false, 0u);
-        kt.begin(2);
-        rtLaunchShade(cfg, ctx->dev, q, par, max_depth, f.spp, (uint32_t)(j * pl.tiles), d_primid, stats >= 2, max_inputs);
-        kt.end();
-        enter(j + 1, par);
-        kt.begin(3);
-        rtLaunchSplitRounds(cfg, ctx->dev, root, q, par, stats);
-        if (q.occ0 && q.prim_n) rtLaunchFold0(cfg, q, nlights);
-        kt.end();
-        if (j >= (size_t)max_depth) {  // the chunk whose deepest level was just shaded and whose last shadow rays were traced
-            const size_t c = j - (size_t)max_depth;
-            kt.begin(4);
-            rtLaunchResolve(cfg, f, q, sample0(c), (uint32_t)(c * pl.tiles), ntilesOf(c), d_rgb8, d_rgbf);
+    for (int l = 0; l < lanes; l++) {
+        rtLaunchIterCtl(L[l].cfg, q0[l], 1, primN(l, 1), true, primN(l, 0));
+        enter(l, 0, -1);
+    }
+    for (size_t j = 0; j < Tmax; j++) {
+        for (int l = 0; l < lanes; l++) {  // (the lanes' launches are enqueued alternately: both streams stay fed)
+            if (j >= L[l].T) continue;
+            const RtLaunchCfg &cfg = L[l].cfg;
+            const int par = (int)(j & 1);
+            RtQueues q = q0[l];
+        q.tile_stride = (uint32_t)nchunks;
+            q.prim_n = primN(l, j);
+            q.prim_sample0 = j < L[l].nk ? sample0(j) : 0u;
+            q.l0_sample0 = q.prim_sample0;
+            if (j > 0) rtLaunchIterCtl(cfg, q, par ^ 1, primN(l, j + 1), false, 0u);
+            kt.stream = cfg.stream;
+            kt.begin(2);
+            probe(q, 2, (uint32_t)rtShadeWaves(cfg));
+            rtLaunchShade(cfg, ctx->dev, q, par, max_depth, f.spp, (uint32_t)chunkOf(l, j), d_primid, stats >= 2, max_inputs, 1);
+            probe(q, 7, (uint32_t)rtShadeWaves(cfg));
+            rtLaunchShade(cfg, ctx->dev, q, par, max_depth, f.spp, (uint32_t)chunkOf(l, j), d_primid, stats >= 2, max_inputs, 2);
             kt.end();
+            enter(l, j + 1, par);
+            kt.stream = cfg.stream;
+            kt.begin(3);
+            rtLaunchSplitRounds(cfg, ctx->dev, root, q, par, stats);
+            if (q.occ0 && q.prim_n) rtLaunchFold0(cfg, q, nlights);
+            kt.end();
+            if (j >= (size_t)max_depth) {  // the chunk whose deepest level was just shaded and whose last shadow rays were traced
+                const size_t jc = j - (size_t)max_depth, c = chunkOf(l, jc);
+                kt.begin(4);
+                rtLaunchResolve(cfg, f, q, sample0(jc), (uint32_t)c, ntilesOf(c), d_rgb8, d_rgbf);
+                kt.end();
+            }
         }
     }
-    rtLaunchIterCtl(cfg, q0, (int)((T - 1) & 1), 0u, false, 0u);  // the last iteration's counters -> totals
+    for (int l = 0; l < lanes; l++) rtLaunchIterCtl(L[l].cfg, q0[l], (int)((L[l].T - 1) & 1), 0u, false, 0u);  // the last iteration's counters -> totals
+    if (lanes > 1) {
+        HIPOK(hipEventRecord(ctx->ev_join, streams[1]));
+        HIPOK(hipStreamWaitEvent(streams[0], ctx->ev_join, 0));
+    }
+    kt.stream = streams[0];
     return 0;
 }
 
@@ -392,11 +466,11 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     EventPair ev;
     if (ev.create()) return 1;
 
-    // Planning.  The workspace is one arena of at most RT_WORKSPACE_GB (24 GiB; never more than 7/8 of what is free on the
+    // Planning.  The workspace is one arena of at most RT_WORKSPACE_GB (30 GiB; never more than 7/8 of what is free on the
     // device, RT_WORKSPACE_FRACTION): the frame is cut into the fewest equal chunks whose queues fit it.  Queue capacities
     // per sample: the WORST case (every hit spawns a pair, every light faces every hit) for the first frame after
     // rt_commit -- 5-20 x what scenes produce, so that frame takes more, smaller chunks, which the pipeline makes cheap --
-    // afterwards 1.5 x the fan-out observed on the scene.  A frame that overflows its queues after all (the kernels drop and
+    // afterwards 1.25 x the fan-out observed on the scene.  A frame that overflows its queues after all (the kernels drop and
     // count what does not fit; nothing is written out of bounds) is rendered again with worst-case queues: every output
     // pixel is written by the repeat.  A caller-given chunk size is taken as is, with worst-case queues.
     int l0_mode = -1;  // level-0 shadow results stored instead of added: -1 = where it pays (below), 0 = never, 1 = always
@@ -410,12 +484,17 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     in.split_cap = (size_t)1 << 22;  // items per round; a wave that finds no room keeps walking
     if (const char *e = getenv("RT_SPLIT_CAP")) in.split_cap = (size_t)std::max(64, atoi(e));  // (test knob: forces the no-room path)
     if (const char *e = getenv("RT_CHUNK_MARGIN")) in.margin = atof(e);  // (test knob: < 1 forces the overflow-and-repeat path)
-    double ws_gb = 24.0, ws_frac = 0.875;
+    double ws_gb = 30.0, ws_frac = 0.875;
     if (const char *e = getenv("RT_WORKSPACE_GB")) ws_gb = std::max(0.001, atof(e));
     if (const char *e = getenv("RT_WORKSPACE_FRACTION")) ws_frac = std::min(0.875, std::max(0.01, atof(e)));
     bool fuse = true;  // RT_FUSE=0: the traversal phases of an iteration as launches of their own (ms_any / ms_closest / ms_packet)
     if (const char *e = getenv("RT_FUSE")) fuse = atoi(e) != 0;
-    std::vector<uint32_t> hc(RT_CNT_WORDS, 0);
+    // RT_LANES=2: two pipelines side by side.  Measured on the 4K frame: the second lane's launches do fill the ends of the
+    // first one's (one lane with chunks of the same size is 10 % slower), but two lanes halve the chunk a workspace can
+    // hold, which costs what the overlap gains: 463 vs 443-453 ms.  One lane unless asked.
+    in.lanes = 1;
+    if (const char *e = getenv("RT_LANES")) in.lanes = std::max(1, std::min(2, atoi(e)));
+    std::vector<uint32_t> hc(2 * RT_CNT_WORDS, 0);
     bool started = false;  // ev.a is recorded once the workspace exists: ms_total is GPU time, not hipMalloc time
     for (int attempt = 0;; attempt++) {
         // Level-0 shadow results stored instead of added (RtQueues::occ0) where most of the scene's shadow rays are
@@ -446,25 +525,69 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
             else want = std::min(std::max(cap, want), want + want / 8);
         }
         if (ensureArena(ctx, want)) return 1;
-        RtQueues q;
-        carveQueues(ctx->d_arena.p, pl.spec, ctx->d_spill.p, q);
+        RtQueues q[2];
+        for (int l = 0; l < pl.lanes; l++)  // (every lane its own queues, counters and traversal spill area)
+            carveQueues(ctx->d_arena.p + (size_t)l * (pl.bytes / (size_t)pl.lanes), pl.spec, ctx->d_spill.p + (size_t)l * ctx->spill_words, q[l]);
         cfg.shade_slab = pl.z.slab;
         if (getenv("RT_VERBOSE"))
-            std::fprintf(stderr, "[rt] frame: %zu chunks of %zu samples (%d in flight), %s queues %.2f rays + %.2f shadow rays per sample, %.2f GB%s\n",
-                         pl.nchunks, pl.samples, pl.ring, pl.optimistic ? "observed" : "worst-case", pl.ray_fan, pl.sh_fan,
+            std::fprintf(stderr, "[rt] frame: %zu chunks of %zu samples in %d lane(s) (%d in flight per lane), %s queues %.2f rays + %.2f shadow rays per sample, %.2f GB%s\n",
+                         pl.nchunks, pl.samples, pl.lanes, pl.ring, pl.optimistic ? "observed" : "worst-case", pl.ray_fan, pl.sh_fan,
                          (double)pl.bytes / 1e9, in.l0 ? ", level-0 shadow results stored" : "");
         if (!started) {
             HIPOK(hipEventRecord(ev.a, stream));
             started = true;
         }
         rt_stats launches{};
-        if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, per_tile, d_rgb8, d_rgbf, d_primid, stats_on, fuse, kt, &launches)) return 1;
-        HIPOK(hipMemcpyAsync(hc.data(), q.counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        TailProf tp;
+        tp.on = getenv("RT_TAILPROF") != nullptr;
+        if (tp.on) {
+            const size_t slots = 8 * (3 * (pl.nchunks + 16) + 8);
+            if (tp.buf.alloc(slots)) return 1;
+            std::vector<unsigned long long> init(slots);
+            for (size_t k = 0; k < slots; k++) init[k] = (k & 7) < 2 ? ~0ull : 0ull;
+            HIPOK(hipMemcpy(tp.buf.p, init.data(), slots * 8, hipMemcpyHostToDevice));
+        }
+        if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, per_tile, d_rgb8, d_rgbf, d_primid, stats_on, fuse, kt, &launches, &tp)) return 1;
+        for (int l = 0; l < pl.lanes; l++)
+            HIPOK(hipMemcpyAsync(hc.data() + (size_t)l * RT_CNT_WORDS, q[l].counters, RT_CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPOK(hipEventRecord(ev.b, stream));
         HIPOK(hipStreamSynchronize(stream));
         HIPOK(hipGetLastError());
+        if (tp.on) {
+            std::vector<unsigned long long> h(8 * tp.recs.size());
+            HIPOK(hipMemcpy(h.data(), tp.buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+            double dur[8] = {0}, tail[8] = {0}, ramp_idle[8] = {0}, ramp[8] = {0}, mtail[8] = {0}, lstart[8] = {0};
+            int cnt[8] = {0};
+            for (size_t k = 0; k < tp.recs.size(); k++) {
+                const unsigned long long *r = h.data() + 8 * k;
+                if (r[2] == 0) continue;
+                const int c = tp.recs[k].cls;
+                const double d = (double)(r[2] - r[0]) / 100.0;  // us
+                dur[c] += d;
+                tail[c] += (double)(r[2] - r[1]) / 100.0;
+                ramp_idle[c] += d - (double)r[3] / 100.0 / tp.recs[k].waves;  // launch duration minus the mean wave lifetime
+                const double mean_end = (double)r[5] / tp.recs[k].waves, mean_life = (double)r[3] / tp.recs[k].waves;
+                ramp[c] += (mean_end - mean_life - (double)r[0]) / 100.0;   // mean wave start after the first wave's
+                mtail[c] += ((double)r[2] - mean_end) / 100.0;               // mean wave end before the last wave's
+                lstart[c] += (double)(r[4] - r[0]) / 100.0;                  // last wave start after the first
+                cnt[c]++;
+            }
+            for (int c = 0; c < 8; c++)
+                if (cnt[c])
+                    std::fprintf(stderr, "[rt] tailprof class %d: %d launches, mean duration %.0f us, first wave done %.0f us before the last, "
+                                 "mean wave absent for %.0f us of a launch: starts %.0f us after the first (last start %.0f us), ends %.0f us before the last\n",
+                                 c, cnt[c], dur[c] / cnt[c], tail[c] / cnt[c], ramp_idle[c] / cnt[c], ramp[c] / cnt[c], lstart[c] / cnt[c], mtail[c] / cnt[c]);
+            tp.buf.release();
+        }
         st->chunks += pl.nchunks;
-        const uint64_t *tot = reinterpret_cast<const uint64_t *>(hc.data() + RT_CNT_TOTALS);
+        uint64_t tot[RT_TOT_WORDS];  // the lanes' totals together (sums; the fullest queue of either)
+        for (int k = 0; k < RT_TOT_WORDS; k++) {
+            tot[k] = 0;
+            for (int l = 0; l < pl.lanes; l++) {
+                const uint64_t v = reinterpret_cast<const uint64_t *>(hc.data() + (size_t)l * RT_CNT_WORDS + RT_CNT_TOTALS)[k];
+                tot[k] = (k == RT_TOT_MAX_RAYS || k == RT_TOT_MAX_SHADOW) ? std::max(tot[k], v) : tot[k] + v;
+            }
+        }
         if (tot[RT_TOT_OVERFLOW] && pl.optimistic) {  // the scene out-grew what was seen so far: again, sized for the worst case
             st->chunk_retries += pl.nchunks;
             ctx->obs_valid = false;
@@ -473,7 +596,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         }
         st->launches_closest = launches.launches_closest;
         st->launches_any = launches.launches_any;
-        addCounters(st, hc.data());
+        for (int l = 0; l < pl.lanes; l++) addCounters(st, hc.data() + (size_t)l * RT_CNT_WORDS);
         if (!tot[RT_TOT_OVERFLOW] && n_local > 0) {
             // Fan-out for the next frames: the frame's mean (every level of a sample is in flight at once in steady state) or
             // the fullest queue seen, whichever is larger -- without the slab slack that queueSizes adds back.
@@ -556,7 +679,7 @@ int renderTilesStatic(rt_context *ctx, const rt_camera *cam, const rt_render_par
     RtQueues q;
     carveQueues((unsigned char *)ctx->scratch, pl.spec, ctx->d_spill.p, q);
     KernelTimer kt;  // (off)
-    if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, true, kt, nullptr)) return 1;
+    if (enqueueFrame(ctx, cfg, f, pl, &q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, true, kt, nullptr)) return 1;
     HIPOK(hipGetLastError());
     return 0;
 }

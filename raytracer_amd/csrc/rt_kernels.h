@@ -31,7 +31,7 @@ void rtLaunchClosest(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root
 void rtLaunchAny(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
 void rtLaunchSplitRounds(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, int par, int stats);
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int par, int max_depth, int spp,
-                   uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs);
+                   uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs, int which = 0);  // which: 0 both instances, 1 fast, 2 general
 // waves of a k_shade launch: each owns up to (lights + 1) partly filled output slabs at the end (queue slack, rt_abi.cpp)
 inline int rtShadeBlocks(const RtLaunchCfg &cfg) { return cfg.shade_blocks > 0 ? cfg.shade_blocks : cfg.num_cus * RT_SHADE_BLOCKS_PER_CU; }
 inline int rtShadeWaves(const RtLaunchCfg &cfg) { return rtShadeBlocks(cfg) * (RT_BLOCK / 64); }

@@ -32,6 +32,21 @@ RT_DEV uint32_t waveReserve(uint32_t *counter, uint32_t total) {
     return __builtin_amdgcn_readfirstlane(base);
 }
 
+// RT_TAILPROF: when the waves of a launch start and end (RtQueues::tailprof)
+RT_DEV unsigned long long rtTailBegin(const RtQueues &q) { return q.tailprof ? wall_clock64() : 0ull; }
+RT_DEV void rtTailEnd(const RtQueues &q, unsigned long long t0) {
+    if (q.tailprof && laneId() == 0) {
+        const unsigned long long t1 = wall_clock64();
+        unsigned long long *p = q.tailprof + 8ull * q.launch_id;
+        atomicMin(p + 0, t0);
+        atomicMin(p + 1, t1);
+        atomicMax(p + 2, t1);
+        atomicAdd(p + 3, t1 - t0);
+        atomicMax(p + 4, t0);
+        atomicAdd(p + 5, t1);
+    }
+}
+
 // Adds (x, y, z) to the fixed-point accumulator of `sample` for every lane with `on`.  What these atomics cost is the
 // L2 atomic units' time per lane operation, and the rays of one sample (a reflection/refraction pair, their children,
 // the shadow rays those cast towards one light) sit in neighbouring queue slots, hence mostly in neighbouring lanes:
@@ -60,6 +75,53 @@ RT_DEV void accumulateRuns(long long *accum, bool on, uint32_t sample, V3 c) {
         atomicAdd(acc + 1, (unsigned long long)fy);
         atomicAdd(acc + 2, (unsigned long long)fz);
     }
+}
+
+// Work cursors of the kernels that deal out a queue dynamically (k_shade's segments, the packet batches; the per-lane
+// walks have the same scheme inline).  The queue [first, n) is cut into RT_WORK_PARTS contiguous parts with a cursor each,
+// on its own 128-byte line: a returning atomic on ONE address retires every ~10-15 ns chip-wide, which a launch of a few
+// million entries fetched 64-1024 at a time reaches.  A wave starts in the part of its XCD (workgroups go round-robin over
+// the 8 XCDs) and moves on when a part is used up.  All 64 lanes call these together; everything is wave-uniform.
+struct RtPartCursor {
+    uint32_t *cursors;
+    uint32_t first, n, part_len, part, parts_done;
+    uint32_t seen;  // how far the current part had got at this wave's last fetch
+};
+RT_DEV RtPartCursor rtPartCursor(uint32_t *cursors, uint32_t first, uint32_t n, uint32_t gran) {
+    RtPartCursor c;
+    c.cursors = cursors;
+    c.first = first;
+    c.n = n;
+    const uint32_t span = n > first ? n - first : 0u;
+    c.part_len = ((span + RT_WORK_PARTS - 1) / RT_WORK_PARTS + gran - 1) / gran * gran;
+    c.part = blockIdx.x % RT_WORK_PARTS;
+    c.parts_done = 0;
+    c.seen = 0;
+    return c;
+}
+// entries of the current part that nobody had claimed at this wave's last fetch (guides the size of the next one: towards
+// the end of a queue a wave takes less, so that a launch does not end with a few waves working off large last helpings)
+RT_DEV uint32_t rtPartLeft(const RtPartCursor &c) {
+    const uint32_t lo = c.first + c.part * c.part_len, hi = min(lo + c.part_len, c.n);
+    return hi > lo + c.seen ? hi - lo - c.seen : 0u;
+}
+RT_DEV bool rtPartFetch(RtPartCursor &c, uint32_t want, uint32_t &base, uint32_t &end) {
+    while (c.parts_done < RT_WORK_PARTS) {
+        const uint32_t lo = c.first + c.part * c.part_len, hi = min(lo + c.part_len, c.n);
+        uint32_t b = 0;
+        if (laneId() == 0) b = atomicAdd(c.cursors + c.part * RT_CNT_STRIDE, want);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (lo < c.n && lo + b < hi) {
+            base = lo + b;
+            end = min(base + want, hi);
+            c.seen = b + want;
+            return true;
+        }
+        c.part = c.part + 1 == RT_WORK_PARTS ? 0u : c.part + 1;  // this part is used up: on to the next
+        c.parts_done++;
+        c.seen = 0;
+    }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -375,8 +437,11 @@ RT_DEV void flushStats(uint32_t *counters, const RtTraversalStats &st, int nodes
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// tile / sample indexing.  A chunk covers local tiles [tile0, tile0 + ntiles); sample index inside the chunk:
-//   ((tile - tile0) * 256 + m) * spp + s,   m = Morton index of the pixel inside its 16x16 tile
+// tile / sample indexing.  A chunk covers the local tiles tile0, tile0 + stride, tile0 + 2 stride, ... (ntiles of them;
+// stride = q.tile_stride = the frame's number of chunks: every chunk is a sample of the WHOLE image, so all chunks hold the
+// same mix of cheap and expensive tiles, every iteration of the pipeline carries the same load, and the fan-out seen on one
+// frame sizes the queues of any other cut of it).  Sample index inside the chunk, k = 0 .. ntiles - 1:
+//   (k * 256 + m) * spp + s,   m = Morton index of the pixel inside its 16x16 tile
 // so that a wave's 64 lanes are 64/spp neighbouring pixels (a 4x4 block at 4 spp) x spp samples.
 RT_DEV uint32_t compact1By1(uint32_t x) {
     x &= 0x55555555u;
@@ -394,7 +459,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
     uint32_t invalid = 0;
     for (uint32_t idx = blockIdx.x * RT_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * RT_BLOCK) {
         const uint32_t s = idx % (uint32_t)f.spp, pm = idx / (uint32_t)f.spp;
-        const uint32_t m = pm & 255u, lt = tile0 + (pm >> 8);
+        const uint32_t m = pm & 255u, lt = tile0 + (pm >> 8) * q.tile_stride;
         const uint32_t gt = lt * (uint32_t)f.tile_world + (uint32_t)f.tile_rank;
         const int i = (int)((gt % (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m));
         const int j = (int)((gt / (uint32_t)f.tiles_x) * RT_TILE + compact1By1(m >> 1));
@@ -490,7 +555,9 @@ RT_DEV RtTraceLds rtTraceSetup(const RtSceneDev &sc, const RtQueues &q, uint32_t
 
 // L0: level-0 shadow results are stored, not added (RtQueues::occ0) -- an instance of its own, so that the usual one keeps
 // its registers
-template <bool ANY, int STATS, int MODE, bool L0 = false>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
+// TAIL: the queue's last entries are fetched one generation at a time (a launch must not end with a few waves working off
+// large last batches); off where another phase of the same launch follows, whose work fills the chip meanwhile.
+template <bool ANY, int STATS, int MODE, bool L0 = false, bool TAIL = true>  // STATS: 0 none, 1 counters (records fetched, longest walk), 2 + wave-time profile
 RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, const RtTraceLds &tl, int par, uint32_t first, int round,
                        uint32_t budget) {
     constexpr bool COUNT = STATS >= 1, PROF = STATS >= 2;
@@ -523,7 +590,10 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;  // wave-uniform
     uint32_t part_seen = 0;                                // how far the current part had got at this wave's last fetch
-    const uint32_t tail_len = gridDim.x * (RT_BLOCK / 64) / PARTS * batch;  // one full batch per wave of the part
+#ifndef RT_TAIL_FACTOR
+#define RT_TAIL_FACTOR 1u
+#endif
+    const uint32_t tail_len = RT_TAIL_FACTOR * (gridDim.x * (RT_BLOCK / 64) / PARTS * batch);  // RT_TAIL_FACTOR full batches per wave of the part
     bool more = true;                      // wave-uniform: the queue may still hold unclaimed rays
     bool has = false;
     uint32_t ray_i = 0, sample = 0;
@@ -629,7 +699,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 const uint32_t lo = first + part * part_len, hi = min(lo + part_len, n);
                 // (two batch sizes: one generation of rays once the part is nearly used up -- as far as this wave knows from
                 // its previous fetch -- so that a launch does not end with a few waves walking 256 rays each)
-                const uint32_t want = lo + part_seen + tail_len >= hi ? 64u : batch;
+                const uint32_t want = TAIL && lo + part_seen + tail_len >= hi ? 64u : batch;
                 uint32_t base = 0;
                 if (laneId() == 0) base = atomicAdd(PARTS > 1 ? work_parts + part * RT_CNT_STRIDE : work, want);
                 base = __builtin_amdgcn_readfirstlane(base);
@@ -1001,24 +1071,18 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtTraceLds &tl, uint32_t roo
 template <bool STATS>
 RT_DEV void packetQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &q, const RtTraceLds &tl, int par) {
     const uint32_t n = min(q.prim_n, q.ray_cap);
-    uint32_t *work = q.counters + RT_CNT_PWORK(par);
     // STATS: [0] packets, [1] node steps, [2] lanes interested in a child per node step, [3] triangle steps, [4] live
     // lanes per triangle step, [5] packets over budget, [6] octant groups walked, [7] rays that finished as per-lane walks
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // Guided batches: a wave walks the packets of its batch one after the other, so the last batches of a launch keep a
-    // few waves busy for RT_PACKET_BATCH packets while the chip idles.  Towards the end of the queue a wave takes fewer
-    // packets per fetch; how far the queue has got is known from its previous fetch.
-    const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64);
-    uint32_t seen = 0;
+    // Guided batches: a wave walks the packets of its batch one after the other, so large last batches would keep a few
+    // waves busy while the chip idles: a wave takes up to RT_PACKET_BATCH packets per fetch, fewer once its part of the
+    // queue runs out (half of what is left per wave of the part).
+    RtPartCursor pc = rtPartCursor(q.counters + RT_CNT_WORKP_PACKET(par, 0), 0u, n, 64u * RT_PACKET_BATCH);
+    const uint32_t waves_per_part = max(1u, gridDim.x * (RT_BLOCK / 64) / RT_WORK_PARTS);
     for (;;) {
-        const uint32_t left = n > seen ? n - seen : 0u;
-        const uint32_t want = 64u * min((uint32_t)RT_PACKET_BATCH, max(1u, left / (128u * nwaves)));
-        uint32_t base = 0;
-        if (laneId() == 0) base = atomicAdd(work, want);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
-        seen = base + want;
-        const uint32_t end = min(base + want, n);
+        const uint32_t want = 64u * min((uint32_t)RT_PACKET_BATCH, max(1u, rtPartLeft(pc) / (128u * waves_per_part)));
+        uint32_t base, end;
+        if (!rtPartFetch(pc, want, base, end)) break;
         for (uint32_t pb = base; pb < end; pb += 64u) {
             if (STATS) prof[0]++;
             tracePacket<STATS>(sc, tl, root_ref, q, par, pb, n, prof);
@@ -1041,12 +1105,21 @@ template <int STATS, bool L0>
 __global__ __launch_bounds__(RT_BLOCK, 8) void k_trace(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par_any, int par_closest, uint32_t first,
                                                        int packets, int stack_entries, uint32_t budget) {
     extern __shared__ uint32_t s_lds[];
+    const unsigned long long tp0 = rtTailBegin(q);
     const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
-    if (par_any >= 0) traceQueue<true, STATS, RT_MODE_QUEUE, L0>(sc, root_ref, q, tl, par_any, 0u, -1, budget);
+#ifndef RT_FUSED_TAIL   // (1: the phases of the fused launch keep their one-generation fetches at the end of their queues)
+#define RT_FUSED_TAIL 0
+#endif
+    if (par_any >= 0) {
+        if (par_closest >= 0 && !RT_FUSED_TAIL) traceQueue<true, STATS, RT_MODE_QUEUE, L0, false>(sc, root_ref, q, tl, par_any, 0u, -1, budget);
+        else traceQueue<true, STATS, RT_MODE_QUEUE, L0, true>(sc, root_ref, q, tl, par_any, 0u, -1, budget);
+    }
     if (par_closest >= 0) {
-        traceQueue<false, STATS, RT_MODE_QUEUE>(sc, root_ref, q, tl, par_closest, first, -1, 0u);
+        if (packets && !RT_FUSED_TAIL) traceQueue<false, STATS, RT_MODE_QUEUE, false, false>(sc, root_ref, q, tl, par_closest, first, -1, 0u);
+        else traceQueue<false, STATS, RT_MODE_QUEUE, false, true>(sc, root_ref, q, tl, par_closest, first, -1, 0u);
         if (packets) packetQueue<(STATS != 0)>(sc, root_ref, q, tl, par_closest);
     }
+    rtTailEnd(q, tp0);
 }
 // the phases as launches of their own (per-kernel timing: collect_stats & 2, RT_FUSE=0; rt_trace_batch; the split rounds)
 template <bool STATS>
@@ -1109,6 +1182,7 @@ template <bool PROF, bool GENERAL>
 __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSceneDev sc, RtQueues q, int par, int max_depth, int spp,
                                                    uint32_t tile0, uint32_t *primid_tiles, uint32_t slab) {
     constexpr bool FAST = !GENERAL;
+    const unsigned long long tp0 = rtTailBegin(q);
     // Output slots come from WAVE-PRIVATE slabs: a wave reserves `slab` consecutive slots of the shadow queue per light
     // (and of the next level's ray queue) with one atomic and fills them over its next iterations -- no barrier, no
     // per-iteration atomic, and a slab holds rays towards ONE light, which keeps k_any's batches coherent.  Cursor and
@@ -1119,7 +1193,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     uint32_t gcur = 0, gend = 0;  // the wave's slab of the general list (wave-uniform)
     const uint32_t slabS = slab, slabR = max(slab, 128u);  // one iteration emits at most 64 shadow rays per light, 128 rays
     const int buf = par, nbuf = par ^ 1;
-    const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(par)], q.ray_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap);
+    const uint32_t n = GENERAL ? min(q.counters[RT_CNT_GENERAL(par)], q.general_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap);
     // A wave shades SEGMENTS of consecutive queue entries (consecutive entries are neighbouring samples / hits), so the
     // rays it appends to a slab leave neighbouring points towards one light.  A wave takes its next segment from a
     // cursor (one atomic per segment): segments cost very differently (misses are only scanned), and dealing them out
@@ -1127,7 +1201,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     // queue so that every wave still gets several.
     const uint32_t nwaves = gridDim.x * (RT_BLOCK / 64);
     const uint32_t seg = min(max((n / (nwaves * 8u)) & ~63u, 64u), RT_SHADE_SEGMENT);
-    uint32_t *const segCursor = q.counters + (GENERAL ? RT_CNT_WORK_SHADEG(par) : RT_CNT_WORK_SHADE(par));
+    RtPartCursor segs = rtPartCursor(q.counters + (GENERAL ? RT_CNT_WORKP_SHADEG(par, 0) : RT_CNT_WORKP_SHADE(par, 0)), 0u, n, 64u);
+    auto nextSegment = [&](uint32_t &b, uint32_t &e) { return rtPartFetch(segs, seg, b, e); };
     const uint32_t lane = laneId();
     const int nlights = sc.n_lights;
     uint32_t culled = 0, shaded = 0, zero = 0, l0lit = 0;
@@ -1142,9 +1217,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
     // sample whose ray missed (see below).  Order is kept, so sibling pairs and runs of equal samples stay neighbours.
     __shared__ uint32_t s_ring[RT_BLOCK / 64][128];
     uint32_t *const ring = s_ring[threadIdx.x >> 6];
-    uint32_t seg0 = waveReserve(segCursor, seg);     // wave-uniform scan state (the cursor runs past n by at most one segment per wave)
-    bool moreSeg = seg0 < n;
-    uint32_t scan = seg0, segEnd = min(seg0 + seg, n), head = 0, count = 0;
+    uint32_t scan = 0, segEnd = 0, head = 0, count = 0;  // wave-uniform scan state
+    bool moreSeg = nextSegment(scan, segEnd);
     while (moreSeg || count) {
         while (count < 64 && moreSeg) {
             const uint32_t j = scan + lane;
@@ -1175,7 +1249,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                         gcur += c;
                     }
                     if (gen) {
-                        if (slot < q.ray_cap) q.general[slot] = j;
+                        if (slot < q.general_cap) q.general[slot] = j;
                         else atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                         hit = false;
                     }
@@ -1185,12 +1259,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             if (hit) ring[(head + count + maskRankBelow(hm)) & 127u] = qi;
             count += (uint32_t)__popcll(hm);
             scan += 64;
-            if (scan >= segEnd) {  // next segment of this wave
-                seg0 = waveReserve(segCursor, seg);
-                moreSeg = seg0 < n;
-                scan = seg0;
-                segEnd = min(seg0 + seg, n);
-            }
+            if (scan >= segEnd) moreSeg = nextSegment(scan, segEnd);  // next segment of this wave
         }
         RT_PROF_MARK(2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1221,7 +1290,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             if (kind == RT_ID_SPHERE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.spheres[id & 0xFFFF].object;
             else if (kind == RT_ID_PLANE) prim = RT_PRIM_ANALYTIC | (uint32_t)sc.planes[id & 0xFFFF].object;
             else prim = sc.tri_shade[id & RT_ID_TRI_MASK].prim;
-            primid_tiles[(size_t)(tile0 + (pm >> 8)) * RT_TILE_PIXELS + py * RT_TILE + px] = prim;
+            primid_tiles[(size_t)(tile0 + (pm >> 8) * q.tile_stride) * RT_TILE_PIXELS + py * RT_TILE + px] = prim;
         }
 
         // per-lane state carried from the shading step to the (block-uniform) emission steps
@@ -1369,10 +1438,11 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             const uint32_t room = end - cur;
             uint32_t slot = cur + rank;
             if (c > room) {  // the slab is used up to its last slot, the rest of the rays opens the next one
-                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(par), slabS);
+                const uint32_t sz = slabS;
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(par), sz);
                 if (rank >= room) slot = nbase + (rank - room);
                 cur = nbase + (c - room);
-                end = nbase + slabS;
+                end = nbase + sz;
             } else {
                 cur += c;
             }
@@ -1402,7 +1472,8 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             const uint32_t room = end - cur;
             uint32_t slot = cur + off;
             if (c > room) {
-                const uint32_t nbase = waveReserve(q.counters + RT_CNT_RAYS(nbuf), slabR);
+                const uint32_t sz = slabR;
+                const uint32_t nbase = waveReserve(q.counters + RT_CNT_RAYS(nbuf), sz);
                 // first lane whose rays do not fit any more: it and the lanes after it move to the new slab
                 const unsigned long long nofit = __ballot(k > 0 && off + k > room);
                 const uint32_t f = (uint32_t)__ffsll((long long)nofit) - 1u;
@@ -1413,7 +1484,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                     holesR++;
                 }
                 cur = nbase + (c - off_f);
-                end = nbase + slabR;
+                end = nbase + sz;
             } else {
                 cur += c;
             }
@@ -1460,7 +1531,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         if (lane == 0 && end > cur) holesR += end - cur;
     }
     if (!GENERAL)  // unused slots of the general list's slab: holes the general instance's scan skips
-        for (uint32_t sl = gcur + lane; sl < min(gend, q.ray_cap); sl += 64) q.general[sl] = RT_GENERAL_HOLE;
+        for (uint32_t sl = gcur + lane; sl < min(gend, q.general_cap); sl += 64) q.general[sl] = RT_GENERAL_HOLE;
     if (PROF && lane == 0) {
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(q.counters + RT_CNT_PROF_SHADE);
         for (int k = 0; k < 6; k++) atomicAdd(dst + k, prof[k]);
@@ -1483,6 +1554,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         if (holesS) atomicAdd(q.counters + RT_CNT_SHADOW_HOLES, holesS);
         if (holesR) atomicAdd(q.counters + RT_CNT_INVALID, holesR);  // ray-queue holes are invalid slots like those of k_gen_primary
     }
+    rtTailEnd(q, tp0);
 }
 
 // Level-0 shadow results that k_any stored instead of adding (RtQueues::occ0): one lane per sample of the chunk that entered
@@ -1544,12 +1616,12 @@ __global__ void k_iter_ctl(RtQueues q, int prev, uint32_t prim_next, int set_cur
     c[RT_CNT_RAYS(prev)] = prim_next;
     c[RT_CNT_SHADOW(prev)] = 0;
     c[RT_CNT_GENERAL(prev)] = 0;
-    c[RT_CNT_WORK_SHADE(prev)] = 0;
-    c[RT_CNT_PWORK(prev)] = 0;
-    c[RT_CNT_WORK_SHADEG(prev)] = 0;
     for (int k = 0; k < RT_WORK_PARTS; k++) {
         c[RT_CNT_WORKP_CLOSEST(prev, k)] = 0;
         c[RT_CNT_WORKP_ANY(prev, k)] = 0;
+        c[RT_CNT_WORKP_PACKET(prev, k)] = 0;
+        c[RT_CNT_WORKP_SHADE(prev, k)] = 0;
+        c[RT_CNT_WORKP_SHADEG(prev, k)] = 0;
     }
     if (set_cur) c[RT_CNT_RAYS(prev ^ 1)] = prim_cur;
 }
@@ -1571,7 +1643,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(RtFrameDev f, RtQueues q, 
             sum.z += gclamp(rtFromFixed(a[2]), 0.0f, 1.0f);
         }
         sum = sum / (float)f.spp;
-        const size_t o = ((size_t)(tile0 + (pm >> 8)) * RT_TILE_PIXELS + py * RT_TILE + px) * 3;
+        const size_t o = ((size_t)(tile0 + (pm >> 8) * q.tile_stride) * RT_TILE_PIXELS + py * RT_TILE + px) * 3;
         if (rgbf_tiles) {
             rgbf_tiles[o] = sum.x;
             rgbf_tiles[o + 1] = sum.y;
@@ -1767,15 +1839,17 @@ void rtLaunchSplitRounds(const RtLaunchCfg &cfg, const RtSceneDev &sc, uint32_t 
 #undef RT_LAUNCHA
 #undef RT_BY_STATS
 void rtLaunchShade(const RtLaunchCfg &cfg, const RtSceneDev &sc, const RtQueues &q, int par, int max_depth, int spp,
-                   uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs) {
+                   uint32_t tile0, uint32_t *primid_tiles, bool prof, uint64_t max_inputs, int which) {
     const uint32_t slab = rtShadeSlab(cfg, max_inputs);
     const dim3 grid(rtShadeBlocks(cfg)), block(RT_BLOCK);
     // the fast instance first (it fills the general list), then -- only for scenes that hold spheres / cones, BMP-textured
     // or anisotropic materials -- the general instance over that list.  Both reserve slabs: the queue slack covers two
     // partly filled slabs per wave and queue (rt_abi.cpp: queueSizes).
-    if (prof) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
-    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
-    if (sc.has_general) {
+    if (which != 2) {
+        if (prof) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
+        else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
+    }
+    if (sc.has_general && which != 1) {
         if (prof) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
         else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, cfg.stream, sc, q, par, max_depth, spp, tile0, primid_tiles, slab);
     }

@@ -191,10 +191,15 @@ struct RtQueues {
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
     uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
-    uint32_t ray_cap, shadow_cap, split_cap;
+    uint32_t ray_cap, shadow_cap, split_cap, general_cap;
+    // RT_TAILPROF (diagnosis): per launch {first wave start, first wave end, last wave end, sum of wave lifetimes, last wave
+    // start, sum of wave ends} in 100 MHz ticks, at tailprof[8 * launch_id]; null = off
+    unsigned long long *tailprof;
+    uint32_t launch_id;
     // this iteration (set by the host per launch): entries [0, prim_n) of the current ray queue are the primary rays of the
     // chunk that enters the pipeline -- level 0, entry k belongs to ring sample prim_sample0 + k
     uint32_t prim_n, prim_sample0;
+    uint32_t tile_stride;      // local tiles of a chunk: tile0 + k * tile_stride (tile0 = the chunk's number, stride = chunks of the frame)
     uint32_t l0_sample0;       // ring sample of the first level-0 shadow ray's chunk (the fused k_trace walks the shadow rays of
                                // iteration j next to the primary rays of chunk j + 1, which prim_n / prim_sample0 then describe)
     uint32_t sample_mask;      // tag & sample_mask = ring sample
@@ -229,9 +234,6 @@ struct RtQueues {
 #define RT_CNT_UNOCCLUDED (14 * RT_CNT_STRIDE + 4)           // u64: shadow rays that reached their light (stats build)
 #define RT_CNT_SHADOW_L0 (14 * RT_CNT_STRIDE + 12)           // shadow rays emitted by level-0 hits (decides RtQueues::occ0)
 #define RT_CNT_GENERAL(p) ((15 + (p)) * RT_CNT_STRIDE)       // hits of iteration parity p left to the general k_shade
-#define RT_CNT_WORK_SHADE(p) ((17 + (p)) * RT_CNT_STRIDE)    // next unclaimed segment of ray queue p (fast k_shade)
-#define RT_CNT_PWORK(p) ((19 + (p)) * RT_CNT_STRIDE)         // next unclaimed packet batch (packet kernel)
-#define RT_CNT_WORK_SHADEG(p) ((21 + (p)) * RT_CNT_STRIDE)   // next unclaimed segment of the general list (general k_shade)
 // Frame totals (u64 each, one line): k_iter_ctl moves the per-iteration 32-bit counters here after every iteration, so
 // that no 32-bit counter has to hold more than one iteration's worth
 #define RT_CNT_TOTALS (23 * RT_CNT_STRIDE)
@@ -255,10 +257,14 @@ struct RtQueues {
 #define RT_CNT_WORKP_BASE (24 * RT_CNT_STRIDE)
 #define RT_CNT_WORKP_CLOSEST(p, k) (RT_CNT_WORKP_BASE + ((p) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)
 #define RT_CNT_WORKP_ANY(p, k) (RT_CNT_WORKP_BASE + ((2 + (p)) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)
+#define RT_CNT_WORKP_PACKET(p, k) (RT_CNT_WORKP_BASE + ((4 + (p)) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)  // primary rays of queue p (packets)
+#define RT_CNT_WORKP_SHADE(p, k) (RT_CNT_WORKP_BASE + ((6 + (p)) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)   // segments of ray queue p (fast k_shade)
+#define RT_CNT_WORKP_SHADEG(p, k) (RT_CNT_WORKP_BASE + ((8 + (p)) * RT_WORK_PARTS + (k)) * RT_CNT_STRIDE)  // segments of the general list (general k_shade)
+#define RT_CNT_WORKP_KINDS 10
 // split rounds of the shadow kernels (rt_kernels.hip, "long any-hit walks"): per parity and round the number of work
 // items queued for it (+0) and the next unclaimed one (+1)
 #define RT_SPLIT_ROUNDS 6
-#define RT_CNT_SPLIT_BASE (RT_CNT_WORKP_BASE + 4 * RT_WORK_PARTS * RT_CNT_STRIDE)
+#define RT_CNT_SPLIT_BASE (RT_CNT_WORKP_BASE + RT_CNT_WORKP_KINDS * RT_WORK_PARTS * RT_CNT_STRIDE)
 #define RT_CNT_SPLIT(p, round) (RT_CNT_SPLIT_BASE + ((p) * (RT_SPLIT_ROUNDS + 1) + (round)) * 2)
 #define RT_CNT_WORDS (RT_CNT_SPLIT_BASE + RT_CNT_STRIDE)  // (2 parities x 7 rounds x 2 words fit one stride)
 #define RT_SPLIT_NULL 0xFFFFFFFFu     // ray index of an item that holds no work (reserved slots of a wave that could not export)
