@@ -51,12 +51,50 @@ def cpu_baseline(scene_name, sample_w, sample_h):
                              cwd=os.path.join(REPO, "assets"), capture_output=True, text=True, check=True).stdout
         info = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
         return {"value": rays / info["render_s"] / 1e6, "unit": "Mrays/s", "cores": info["threads"], "kind": "reference",
+                "build": "g++ -std=c++17 -Ofast -fopenmp oracle/ref_harness.cpp (includes /root/reference/main.cpp; oracle/Makefile)",
                 "sample": sample + ", reference built g++ -Ofast -fopenmp", "seconds": info["render_s"],
                 "primary_samples_per_s": sample_w * sample_h * 4 / info["render_s"],
                 "port_mrays_per_s": rays / port_s / 1e6}
     return {"value": rays / port_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "build": "g++ -O2 -fopenmp oracle/rt_oracle.cpp (oracle/Makefile)",
             "sample": sample + ", oracle/rt_oracle.cpp -O2 -fopenmp", "seconds": port_s,
             "primary_samples_per_s": sample_w * sample_h * 4 / port_s}
+
+
+def multi_abi(a):
+    """--multi-abi: the frame over N GPUs of ONE process through rt_multi_* (one host thread per GPU inside the library, RCCL
+    send/recv at frame end).  `value` covers rt_multi_render as a C++ host calls it: it ends with the images in HOST buffers."""
+    from raytracer_amd import FlatScene
+    from raytracer_amd.renderer import MultiRenderer
+    devices = [int(x) for x in a.multi_devices.split(",")] if a.multi_devices else list(range(a.gpus))
+    scene = FlatScene.builtin(a.scene)
+    m = MultiRenderer(devices, rehearse_rccl=len(devices) == 1).set_scene(scene)
+    W, H = a.width, a.height
+    kw = dict(spp=a.spp, max_depth=a.depth, chunk_samples=a.chunk, want=("rgb8", "primid"))
+    for _ in range(a.warmup):
+        m.render(W, H, **kw)
+    t0 = time.perf_counter()
+    rays = zero = prim = 0
+    for _ in range(a.steps):
+        out = m.render(W, H, **kw)
+        for st in out["stats"]:
+            rays += st["rays_closest"] + st["rays_shadow"]
+            zero += st["shadow_zero"]
+            prim += st["primary_samples"]
+    dt = time.perf_counter() - t0
+    result = {
+        "metric": "Mrays/s", "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": len(devices), "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / max(a.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "reference scene assets (meshes/*.obj), synthetic camera samples",
+        "config": {"workload": f"{a.scene} scene {W}x{H} @{a.spp}spp depth {a.depth}", "triangles": scene.n_triangles,
+                   "parallelism": f"tiles%{len(devices)}", "devices": devices},
+        "primary_samples_per_s": prim / dt, "rays_per_primary": rays / max(prim, 1),
+        "multi": dict(out["timings"], path="rt_multi_* (C ABI, one process, one host thread per GPU), transport " + m.transport,
+                      share_ms=[st["ms_total"] for st in out["stats"]], chunks_per_share=[st["chunks"] for st in out["stats"]],
+                      note="timings of the last frame; ms_per_step includes the read-back of the images to host buffers (ms_readback)"),
+    }
+    print(json.dumps(result), flush=True)
+    m.close()
 
 
 def main():
@@ -75,6 +113,11 @@ def main():
     ap.add_argument("--cpu-sample", default="480x360")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gather even with one rank (rehearses the RCCL path on a 1-GPU box)")
+    ap.add_argument("--multi-abi", action="store_true",
+                    help="ONE process, N GPUs through the C ABI's rt_multi_* (what a C++ host links) instead of one process per GPU: "
+                         "--gpus N uses devices 0..N-1 (or --multi-devices)")
+    ap.add_argument("--multi-devices", default="", help="with --multi-abi: comma-separated device ids; a repeated id rehearses "
+                                                         "several ranks on one card (exchange by device copies, not RCCL)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N ranks on ONE card: every rank renders on cuda:0 and the gather goes through host tensors and gloo "
                          "(RCCL wants one GPU per rank).  Checks the control flow of the N > 1 path on a 1-GPU box, not its speed")
@@ -85,6 +128,8 @@ def main():
     from raytracer_amd import FlatScene
     from raytracer_amd.renderer import Renderer
 
+    if a.multi_abi:
+        return multi_abi(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +194,18 @@ def main():
         dt = float(mx[0])
     rays_all, prim_all, zero_all = float(tot[1]), float(tot[2]), float(tot[3])
 
+    # one more frame with a synchronisation behind the gather and behind the assembly: where a frame's time goes per rank
+    multi = None
+    if use_dist:
+        st_parts = df.render(stream=stream, spp=a.spp, max_depth=a.depth, chunk_samples=a.chunk, time_parts=True)
+        mine = [df.timings["share_ms"], df.timings["gather_ms"], df.timings["assemble_ms"], float(st_parts["chunks"])]
+        parts = [None] * world
+        dist.all_gather_object(parts, mine)
+        multi = {"path": "one process per GPU (torch.distributed, backend %s)" % ("gloo, host-staged" if a.rehearse_gloo else "nccl = RCCL"),
+                 "share_ms": [x[0] for x in parts], "gather_ms_rank0": parts[0][1], "assemble_ms_rank0": parts[0][2],
+                 "chunks_per_share": [int(x[3]) for x in parts],
+                 "note": "share_ms: GPU time of each rank's tiles (HIP events); gather: host wall time from the end of rank 0's render to "
+                         "the end of the gather on rank 0, i.e. it includes waiting for the slowest rank"}
     result = None
     if rank == 0:
         result = {
@@ -157,7 +214,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "reference scene assets (meshes/*.obj), synthetic camera samples",
             "config": {"workload": f"{a.scene} scene {W}x{H} @{a.spp}spp depth {a.depth}", "triangles": scene.n_triangles,
                        "tiles": n_tiles, "parallelism": f"tiles%{world}",
-                       "chunk_samples": a.chunk or "adaptive (fan-out observed on the scene; DESIGN.md 2)",
+                       "chunk_samples": a.chunk or "as many as the workspace holds (fan-out observed on the scene; DESIGN.md 2)",
+                       "workspace_gb": float(os.environ.get("RT_WORKSPACE_GB", "30")),
                        "chunks_per_frame": st["chunks"], "chunk_retries_last_frame": st["chunk_retries"]},
             "primary_samples_per_s": prim_all / dt, "rays_per_primary": rays_all / max(prim_all, 1.0),
             # `value` counts the queries that were TRACED.  The reference casts more: shadow rays whose pending radiance is
@@ -167,6 +225,8 @@ def main():
                      "reference_defined_mrays_per_s": (rays_all + zero_all) / dt / 1e6},
             "ms_per_frame": dt / max(a.steps, 1) * 1e3, "bvh": {"nodes": st["bvh_nodes"], "depth": st["bvh_depth"]},
         }
+        if multi:
+            result["multi"] = multi
     if not a.no_roofline:
         # EVERY rank renders the two instrumented frames: a frame ends in a collective (the gather), so rank 0 alone
         # would wait for peers that have moved on.  The figures reported are rank 0's (its share of the tiles).
@@ -202,15 +262,15 @@ def main():
             qbytes = 40.0 * nrays
         khash = kernel_source_hash()
         traffic, traffic_src = None, "no rocprofv3 --pmc pass of these kernel sources is committed"
-        tpath = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+        tpath = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes of this workload
             t = json.load(open(tpath))
             if t.get("kernel_source_hash") != khash:
-                traffic_src = "profiles/r02_pmc_traffic.json was collected on other kernel sources (hash mismatch): not used"
+                traffic_src = "profiles/r03_pmc_traffic.json was collected on other kernel sources (hash mismatch): not used"
             elif t.get("workload") == result["config"]["workload"] and name in t.get("kernels", {}):
                 # per launch of THIS run (the profiled frame may have been cut into more chunks, i.e. more launches)
                 traffic = t["kernels"][name]["hbm_bytes_per_frame"] / launches
-                traffic_src = "profiles/r02_pmc_traffic.json (same kernel sources, hash %s)" % khash
+                traffic_src = "profiles/r03_pmc_traffic.json (same kernel sources, hash %s)" % khash
         result["roofline"] = {
             "kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -227,7 +287,13 @@ def main():
                 "lanes_per_node_phase": pr[3] / pr[2], "lanes_per_triangle_phase": pr[6] / pr[5],
                 "node_phases": pr[2], "triangle_phases": pr[5], "rays_per_refill": pr[9] / pr[8],
                 "note": "of 64 lanes; a phase issues its instructions for the whole wave"}
-        vpath = os.path.join(REPO, "profiles", "r02_pmc_valu.json")
+        cpath = os.path.join(REPO, "profiles", "r03_pmc_cache.json")
+        if os.path.exists(cpath):  # committed L1 / L2 hit-rate passes of this workload: only with matching kernel sources
+            cj = json.load(open(cpath))
+            c = cj.get("kernels", {}).get(name)
+            if cj.get("kernel_source_hash") == khash and c:
+                result["roofline"]["l2"] = dict(c, source="profiles/r03_pmc_cache.json (same kernel sources)")
+        vpath = os.path.join(REPO, "profiles", "r03_pmc_valu.json")
         if os.path.exists(vpath):  # committed rocprofv3 --pmc SQ pass of this workload: only with matching kernel sources
             vj = json.load(open(vpath))
             v = vj.get("kernels", {}).get(name)
@@ -235,7 +301,7 @@ def main():
                 result["roofline"]["issue"] = {
                     "valu_wave_insts_per_ray": v["SQ_INSTS_VALU"] / max(nrays, 1),
                     "valu_issue_frac_of_2cyc_peak": v.get("valu_issue_frac"), "sclk_ghz_profiled": v.get("sclk_ghz"),
-                    "source": "profiles/r02_pmc_valu.json (same kernel sources); see profiles/r02_valu_issue.md"}
+                    "source": "profiles/r03_pmc_valu.json (same kernel sources)"}
         result["kernel_ms"] = {k: timed[k] for k in ("ms_gen", "ms_trace", "ms_packet", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}
     if rank == 0 and not a.no_cpu and world == 1:
         try:
@@ -244,8 +310,10 @@ def main():
         except Exception as e:  # the baseline is a reported number, not a dependency of the measurement
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "unavailable", "sample": repr(e)}
         if result["cpu_baseline"].get("kind") == "port":
-            print("bench.py: oracle/_ref (the compiled reference) is absent: cpu_baseline is the oracle PORT, not the reference",
-                  file=sys.stderr, flush=True)
+            result["cpu_baseline"]["warning"] = ("oracle/_ref (the compiled reference, built by oracle/Makefile where /root/reference "
+                                                 "exists) is ABSENT: this is the oracle PORT, which walks one BVH over all triangles and is "
+                                                 "3-4x faster than the reference -- not comparable with a kind == 'reference' figure")
+            print("bench.py: " + result["cpu_baseline"]["warning"], file=sys.stderr, flush=True)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -280,6 +280,18 @@ int rt_multi_commit(rt_multi *m);
  * p->tile_rank / tile_world are ignored (set per rank). */
 int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8, float *out_rgbf,
                     uint32_t *out_primid, rt_stats *stats);
+/* Where the last rt_multi_render spent its wall time (host clock, ms), so that a scaling loss can be assigned to the tile
+ * partition (ms_share_max vs ms_share_min: GPU time of the slowest / fastest rank's share), to what a share costs over
+ * its ideal 1/N (compare ms_share_max with a one-GPU frame), or to the exchange / assembly / read-back.  No counterpart in
+ * the reference (its only timer wraps the whole program, main.cpp:541,651-653). */
+typedef struct rt_multi_timings {
+    double ms_render_wall; /* all ranks' shares, started together, until the last one has finished */
+    double ms_share_max, ms_share_min;
+    double ms_exchange;    /* the RCCL send/recv group (or the copies) until rank 0 holds every rank's tiles */
+    double ms_assemble;    /* de-interleave on rank 0 */
+    double ms_readback;    /* images to the host buffers */
+} rt_multi_timings;
+int rt_multi_last_timings(const rt_multi *m, rt_multi_timings *out);
 
 /* -- trace_ray-style API (main.cpp:221-233) for batches of arbitrary rays; used by the parity tests -- */
 

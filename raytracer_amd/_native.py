@@ -67,6 +67,14 @@ class Stats(C.Structure):
         return {name: (list(getattr(self, name)) if name.startswith("prof_") else getattr(self, name)) for name, _ in self._fields_}
 
 
+class MultiTimings(C.Structure):
+    _fields_ = [("ms_render_wall", C.c_double), ("ms_share_max", C.c_double), ("ms_share_min", C.c_double),
+                ("ms_exchange", C.c_double), ("ms_assemble", C.c_double), ("ms_readback", C.c_double)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class CommitStats(C.Structure):
     _fields_ = [("n_triangles", C.c_uint64), ("bvh_nodes", C.c_uint64), ("ms_bvh_build", C.c_double),
                 ("ms_reference_order", C.c_double), ("ms_records", C.c_double), ("ms_upload", C.c_double)]
@@ -137,6 +145,7 @@ def hip_lib():
     lib.rt_multi_context.restype = VP
     lib.rt_multi_commit.argtypes = [VP]
     lib.rt_multi_render.argtypes = [VP, P(Camera), P(RenderParams), VP, VP, VP, VP]
+    lib.rt_multi_last_timings.argtypes = [VP, P(MultiTimings)]
     lib.rt_get_commit_stats.argtypes = [VP, P(CommitStats)]
     lib.rt_trace_batch.argtypes = [VP, I64, VP, I32, VP, VP, VP, P(Stats)]
     lib.rt_eval_texture.argtypes = [VP, I32, I64, VP, VP]

@@ -7,6 +7,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -465,7 +467,7 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
         ctx->bvh = RtBvh{};
         ctx->bvh.root_ref = src->bvh.root_ref; ctx->bvh.depth = src->bvh.depth; ctx->bvh.max_stack = src->bvh.max_stack;
         ctx->bvh.bound = src->bvh.bound;
-        ctx->commit_stats = src->commit_stats;
+        // (commit_stats: copied by rt_multi_commit once every upload has finished -- rank 0's thread writes src's meanwhile)
     }
     const size_t nn = src->bvh.nodes.size();
     const int64_t nt = (int64_t)src->tri_flags.size();
@@ -794,8 +796,59 @@ int loadRccl() {
     } while (0)
 }  // namespace
 
+// One host thread per GPU, kept for the life of the rt_multi: a frame hands every worker its rank's share and waits.
+struct RtWorkers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable wake, done;
+    std::function<void(int)> job;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool quit = false;
+    void start(int n) {
+        for (int k = 0; k < n; k++)
+            threads.emplace_back([this, k] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<void(int)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        wake.wait(lk, [&] { return quit || generation != seen; });
+                        if (quit) return;
+                        seen = generation;
+                        f = job;
+                    }
+                    f(k);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) done.notify_all();
+                    }
+                }
+            });
+    }
+    void run(const std::function<void(int)> &f) {  // f(rank) on every worker; returns when all have finished
+        std::unique_lock<std::mutex> lk(mu);
+        job = f;
+        pending = (int)threads.size();
+        generation++;
+        wake.notify_all();
+        done.wait(lk, [&] { return pending == 0; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        wake.notify_all();
+        for (std::thread &t : threads) t.join();
+        threads.clear();
+    }
+};
+
 struct rt_multi {
     int n = 0;
+    RtWorkers workers;
+    rt_multi_timings last{};  // of the last rt_multi_render
     std::vector<int> dev;
     std::vector<rt_context *> ctx;
     bool rccl = false;       // transport of the frame-end exchange: RCCL send/recv, else device-to-device copies
@@ -848,12 +901,14 @@ int rt_multi_create(const int32_t *device_ids, int32_t n, uint32_t flags, rt_mul
             return fail(std::string("rt_multi_create: ncclCommInitAll: ") + g_rccl.errorString(r));
         }
     }
+    m->workers.start(n);
     *out = m;
     return 0;
 }
 
 int rt_multi_destroy(rt_multi *m) {
     if (!m) return 0;
+    m->workers.stop();
     for (int k = 0; k < m->n && k < (int)m->ctx.size(); k++) {
         (void)hipSetDevice(m->dev[k]);
         (void)hipDeviceSynchronize();
@@ -887,15 +942,17 @@ int rt_multi_commit(rt_multi *m) {
     // uploads run concurrently, one host thread per GPU
     std::vector<int> rc(m->n, 0);
     std::vector<std::string> err(m->n);
-    std::vector<std::thread> th;
-    for (int k = 0; k < m->n; k++)
-        th.emplace_back([&, k] {
-            rc[k] = commitDevice(m->ctx[k], src, img);
-            if (rc[k]) err[k] = g_err;
-        });
-    for (std::thread &t : th) t.join();
+    m->workers.run([&](int k) {
+        rc[k] = commitDevice(m->ctx[k], src, img);
+        if (rc[k]) err[k] = g_err;
+    });
     for (int k = 0; k < m->n; k++)
         if (rc[k]) return fail("rt_multi_commit: rank " + std::to_string(k) + ": " + err[k]);
+    for (int k = 1; k < m->n; k++) {  // the replicas report the build's split with their own upload time
+        const double up = m->ctx[k]->commit_stats.ms_upload;
+        m->ctx[k]->commit_stats = src->commit_stats;
+        m->ctx[k]->commit_stats.ms_upload = up;
+    }
     return 0;
 }
 
@@ -924,35 +981,46 @@ int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_params *p
     auto local8 = [&](int k) { return (k == 0 && !m->self_rccl) ? m->g8.p : m->t8[k].p; };  // rank 0 renders into its slot
     auto localf = [&](int k) { return !want_f ? nullptr : (k == 0 && !m->self_rccl) ? m->gf.p : m->tf[k].p; };
     auto localp = [&](int k) { return (k == 0 && !m->self_rccl) ? m->gp.p : m->tp[k].p; };
-    {
-        std::vector<std::thread> th;
-        for (int k = 0; k < n; k++)
-            th.emplace_back([&, k] {
-                rt_render_params q = *p;
-                q.tile_rank = k;
-                q.tile_world = n;
-                rc[k] = renderTiles(m->ctx[k], cam, &q, local8(k), localf(k), localp(k), m->ctx[k]->stream, &st[k]);
-                if (rc[k]) err[k] = g_err;
-            });
-        for (std::thread &t : th) t.join();
-    }
+    const double t_render0 = nowMs();
+    m->workers.run([&](int k) {
+        rt_render_params q = *p;
+        q.tile_rank = k;
+        q.tile_world = n;
+        rc[k] = renderTiles(m->ctx[k], cam, &q, local8(k), localf(k), localp(k), m->ctx[k]->stream, &st[k]);
+        if (rc[k]) err[k] = g_err;
+    });
+    const double t_render1 = nowMs();
     for (int k = 0; k < n; k++)
         if (rc[k]) return fail("rt_multi_render: rank " + std::to_string(k) + ": " + err[k]);
     // ---- the one exchange step ----
     hipStream_t s0 = m->ctx[0]->stream;
     const int first = m->self_rccl ? 0 : 1;
     if (m->rccl) {
-        NCCLOK(g_rccl.groupStart());
-        for (int k = first; k < n; k++) {
-            NCCLOK(g_rccl.recv(m->g8.p + (size_t)k * slot * 3, slot * 3, ncclUint8, k, m->comms[0], s0));
-            NCCLOK(g_rccl.recv(m->gp.p + (size_t)k * slot, slot, ncclUint32, k, m->comms[0], s0));
-            if (want_f) NCCLOK(g_rccl.recv(m->gf.p + (size_t)k * slot * 3, slot * 3, ncclFloat32, k, m->comms[0], s0));
-            hipStream_t sk = m->ctx[k]->stream;
-            NCCLOK(g_rccl.send(m->t8[k].p, slot * 3, ncclUint8, 0, m->comms[k], sk));
-            NCCLOK(g_rccl.send(m->tp[k].p, slot, ncclUint32, 0, m->comms[k], sk));
-            if (want_f) NCCLOK(g_rccl.send(m->tf[k].p, slot * 3, ncclFloat32, 0, m->comms[k], sk));
+        // Every call between ncclGroupStart and ncclGroupEnd is only queued; an early return inside the group would leave
+        // this thread's group open, and every later RCCL call of the thread (torch's included) would queue into it and
+        // never launch.  So: remember the first error, always close the group, then report.
+        ncclResult_t bad = ncclSuccess;
+        const char *where = "";
+        auto note = [&](ncclResult_t r, const char *what) {
+            if (r != ncclSuccess && bad == ncclSuccess) {
+                bad = r;
+                where = what;
+            }
+        };
+        note(g_rccl.groupStart(), "ncclGroupStart");
+        if (bad == ncclSuccess) {
+            for (int k = first; k < n && bad == ncclSuccess; k++) {
+                note(g_rccl.recv(m->g8.p + (size_t)k * slot * 3, slot * 3, ncclUint8, k, m->comms[0], s0), "ncclRecv(rgb8)");
+                note(g_rccl.recv(m->gp.p + (size_t)k * slot, slot, ncclUint32, k, m->comms[0], s0), "ncclRecv(primid)");
+                if (want_f) note(g_rccl.recv(m->gf.p + (size_t)k * slot * 3, slot * 3, ncclFloat32, k, m->comms[0], s0), "ncclRecv(rgbf)");
+                hipStream_t sk = m->ctx[k]->stream;
+                note(g_rccl.send(m->t8[k].p, slot * 3, ncclUint8, 0, m->comms[k], sk), "ncclSend(rgb8)");
+                note(g_rccl.send(m->tp[k].p, slot, ncclUint32, 0, m->comms[k], sk), "ncclSend(primid)");
+                if (want_f) note(g_rccl.send(m->tf[k].p, slot * 3, ncclFloat32, 0, m->comms[k], sk), "ncclSend(rgbf)");
+            }
+            note(g_rccl.groupEnd(), "ncclGroupEnd");
         }
-        NCCLOK(g_rccl.groupEnd());
+        if (bad != ncclSuccess) return fail(std::string("rt_multi_render: ") + where + ": " + g_rccl.errorString(bad));
         for (int k = first; k < n; k++) {  // the peers' sends have left their buffers (next frame may overwrite them)
             if (k == 0) continue;
             HIPOK(hipSetDevice(m->dev[k]));
@@ -968,14 +1036,32 @@ int rt_multi_render(rt_multi *m, const rt_camera *cam, const rt_render_params *p
     }
     // ---- rank 0: de-interleave (stream-ordered behind the receives), hand the image to the host ----
     HIPOK(hipSetDevice(m->dev[0]));
+    HIPOK(hipStreamSynchronize(s0));  // (the exchange alone, for rt_multi_timings; the assembly synchronises anyway)
+    const double t_exchange1 = nowMs();
     if (rt_assemble_tiles_device(m->ctx[0], p->width, p->height, n, per, m->g8.p, want_f ? m->gf.p : nullptr, m->gp.p, m->o8.p,
                                  want_f ? m->of.p : nullptr, m->op.p, s0))
         return 1;
+    const double t_assemble1 = nowMs();
     if (out_rgb8) HIPOK(hipMemcpy(out_rgb8, m->o8.p, npix * 3, hipMemcpyDeviceToHost));
     if (out_rgbf) HIPOK(hipMemcpy(out_rgbf, m->of.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (out_primid) HIPOK(hipMemcpy(out_primid, m->op.p, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (stats)
         for (int k = 0; k < n; k++) stats[k] = st[k];
+    m->last.ms_render_wall = t_render1 - t_render0;
+    m->last.ms_exchange = t_exchange1 - t_render1;
+    m->last.ms_assemble = t_assemble1 - t_exchange1;
+    m->last.ms_readback = nowMs() - t_assemble1;
+    m->last.ms_share_max = m->last.ms_share_min = st[0].ms_total;
+    for (int k = 1; k < n; k++) {
+        m->last.ms_share_max = std::max(m->last.ms_share_max, st[k].ms_total);
+        m->last.ms_share_min = std::min(m->last.ms_share_min, st[k].ms_total);
+    }
+    return 0;
+}
+
+int rt_multi_last_timings(const rt_multi *m, rt_multi_timings *out) {
+    if (!m || !out) return fail("rt_multi_last_timings: NULL argument");
+    *out = m->last;
     return 0;
 }
 

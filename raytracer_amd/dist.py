@@ -64,13 +64,17 @@ class DistributedFrame:
             self.g8 = torch.empty((world,) + tuple(self.t8.shape), dtype=torch.uint8, device=device) if self.collective else None
             self.gp = torch.empty((world,) + tuple(self.tp.shape), dtype=torch.int32, device=device) if self.collective else None
 
-    def render(self, stream=None, **kw):
+    def render(self, stream=None, time_parts=False, **kw):
         """returns this rank's rt_stats dict; on rank 0 self.o8 / self.op hold the assembled image afterwards.
 
         Everything is ordered on ONE stream: torch's current stream of this rank's device unless `stream` (a raw
         hipStream_t) is given -- the render and the assembly are enqueued on it through the C ABI, and the nccl backend
         orders its gather against torch's current stream, so the caller must pass that very stream if it passes one.
-        (0 would mean the context's private non-blocking stream, which the gather is NOT ordered against.)"""
+        (0 would mean the context's private non-blocking stream, which the gather is NOT ordered against.)
+        time_parts: synchronise after the gather and after the assembly and leave {"share_ms", "gather_ms", "assemble_ms"}
+        (this rank's GPU time for its tiles; host wall time of the two steps behind it) in self.timings -- so that a
+        scaling loss can be assigned to the partition, the cost of a share, or the exchange."""
+        import time
         import torch
         if stream is None:
             stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
@@ -80,6 +84,7 @@ class DistributedFrame:
                 torch.cuda.synchronize(self.device)
         st = self.r.render_tiles_device(self.W, self.H, self.rank, self.world, self.t8.data_ptr(), 0, self.tp.data_ptr(),
                                         stream=stream, **kw)   # (complete when the call returns)
+        t_render = time.perf_counter()
         if not self.collective:
             g8, gp = self.t8, self.tp
         elif self.stage_host:
@@ -98,7 +103,13 @@ class DistributedFrame:
             g8, gp = (self.g8, self.gp) if self.rank == 0 else (None, None)
             if stream == 0 and self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)  # the assembly below runs on the context stream: wait for the gather
+        if time_parts and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t_gather = time.perf_counter()
         if self.rank == 0:
             self.r.assemble_tiles_device(self.W, self.H, self.world, self.per, g8.data_ptr(), 0, gp.data_ptr(),
                                          self.o8.data_ptr(), 0, self.op.data_ptr(), stream=stream)
+        if time_parts:
+            self.timings = {"share_ms": st["ms_total"], "gather_ms": (t_gather - t_render) * 1e3,
+                            "assemble_ms": (time.perf_counter() - t_gather) * 1e3}
         return st

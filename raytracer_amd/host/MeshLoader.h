@@ -126,6 +126,11 @@ public:
         // are what %f / %d call) with sscanf's matching rules: a literal must match exactly, white space in the format
         // skips any white space, %f skips leading white space, the first failure ends the line and leaves the
         // remaining targets as they were.
+        // Deliberate difference on MALFORMED numbers (none occur in the reference's assets, so parity is unpinned there,
+        // not broken): glibc's scanf consumes a dangling exponent ("1e", "1.5e+" followed by a non-digit) and then FAILS
+        // the conversion, leaving the target stale and ending the line; strtof -- and this scanner -- convert the mantissa
+        // (1, 1.5) and stop in front of the 'e'.  Integers beyond strtol's range saturate here where %d wraps.
+        // tests/test_host_objscan.py: test_dangling_exponent_follows_strtof states the choice.
         std::string buf;
         {
             FILE *fp = fopen(filename.c_str(), "rb");

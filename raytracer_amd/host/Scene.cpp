@@ -183,13 +183,26 @@ void printIngest(std::FILE *f) {
                  (unsigned long long)t.commit.bvh_nodes, t.commit.ms_reference_order, t.commit.ms_records, t.commit.ms_upload);
 }
 
-rt_context *defaultContext() {
+// the process-wide single-GPU context; `device` >= 0 names the GPU (else RT_DEVICE, else 0).  Asking for another GPU than
+// the one the context lives on replaces it (the scene is uploaded again by the next render()/trace_ray()).
+rt_context *defaultContext(int device) {
     static rt_context *ctx = nullptr;
+    static int ctx_device = -1;
     static std::mutex mu;
     std::lock_guard<std::mutex> g(mu);
-    if (!ctx) {
+    if (device < 0 && !ctx) {
         const char *e = std::getenv("RT_DEVICE");
-        rtCheck(rt_create(e ? std::atoi(e) : 0, &ctx), "rt_create");
+        device = e ? std::atoi(e) : 0;
+    }
+    if (ctx && device >= 0 && device != ctx_device) {
+        if (g_tex_ctx == ctx) g_tex_ctx = nullptr;
+        rt_destroy(ctx);
+        ctx = nullptr;
+        invalidateScene();
+    }
+    if (!ctx) {
+        rtCheck(rt_create(device, &ctx), "rt_create");
+        ctx_device = device;
     }
     return ctx;
 }
@@ -264,9 +277,15 @@ void setTextureDir(const std::string &dir) { g_texture_dir = dir; }
 static rt_multi *g_multi = nullptr;
 static std::vector<int> g_multi_devices;
 static rt_context *rendererContext(const std::vector<int> &devices) {
-    if (devices.size() <= 1 && !g_multi) {
-        if (devices.size() == 1 && !std::getenv("RT_DEVICE")) setenv("RT_DEVICE", std::to_string(devices[0]).c_str(), 0);
-        return defaultContext();
+    if (devices.size() <= 1) {
+        if (g_multi) {  // back from several GPUs to one: the multi-GPU set is given up, the scene goes to the single context
+            if (g_tex_ctx == rt_multi_context(g_multi, 0)) g_tex_ctx = nullptr;
+            rt_multi_destroy(g_multi);
+            g_multi = nullptr;
+            g_multi_devices.clear();
+            g_uploaded = false;
+        }
+        return defaultContext(devices.size() == 1 ? devices[0] : -1);
     }
     if (devices.size() > 1 && (!g_multi || devices != g_multi_devices)) {
         if (g_multi) rt_multi_destroy(g_multi);
@@ -319,10 +338,18 @@ rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
         std::vector<rt_stats> per(rt_multi_size(g_multi));
         rtCheck(rt_multi_render(g_multi, &cam, &p, rgb8.data(), nullptr, nullptr, per.data()), "rt_multi_render");
         st = per[0];
-        for (size_t k = 1; k < per.size(); k++) {  // counts add up over the ranks, the frame takes as long as the slowest
-            st.primary_samples += per[k].primary_samples; st.rays_closest += per[k].rays_closest; st.rays_shadow += per[k].rays_shadow;
-            st.shadow_culled += per[k].shadow_culled; st.hits_shaded += per[k].hits_shaded; st.queue_overflow += per[k].queue_overflow;
-            st.ms_total = std::max(st.ms_total, per[k].ms_total);
+        for (size_t k = 1; k < per.size(); k++) {  // every count adds up over the ranks, the frame takes as long as the slowest
+            const rt_stats &o = per[k];
+            st.primary_samples += o.primary_samples; st.rays_closest += o.rays_closest; st.rays_shadow += o.rays_shadow;
+            st.shadow_culled += o.shadow_culled; st.shadow_zero += o.shadow_zero; st.shadow_unoccluded += o.shadow_unoccluded;
+            st.hits_shaded += o.hits_shaded; st.queue_overflow += o.queue_overflow; st.split_items += o.split_items;
+            st.nodes_visited += o.nodes_visited; st.tris_tested += o.tris_tested;
+            st.nodes_visited_any += o.nodes_visited_any; st.tris_tested_any += o.tris_tested_any;
+            st.chunks += o.chunks; st.chunk_retries += o.chunk_retries;
+            st.launches_closest += o.launches_closest; st.launches_any += o.launches_any;
+            st.max_walk_closest = std::max(st.max_walk_closest, o.max_walk_closest);
+            st.max_walk_any = std::max(st.max_walk_any, o.max_walk_any);
+            st.ms_total = std::max(st.ms_total, o.ms_total);
         }
     } else {
         rtCheck(rt_render(ctx, &cam, &p, rgb8.data(), nullptr, nullptr, &st), "rt_render");
@@ -332,7 +359,7 @@ rt_stats render(Image &image, const Camera &camera, const RenderOptions &opt) {
 }
 
 std::vector<glm::vec3> trace_rays(const std::vector<Ray> &rays, int bounces, std::vector<Hit> *hits) {
-    rt_context *ctx = g_multi ? rt_multi_context(g_multi, 0) : defaultContext();
+    rt_context *ctx = g_multi ? rt_multi_context(g_multi, 0) : defaultContext();  // (the renderer of the last render())
     ensureUploaded(ctx, g_texture_dir);  // the directory of the last render(), or setTextureDir(); default ./textures
     const size_t n = rays.size();
     std::vector<float> in(6 * n), col(3 * n);

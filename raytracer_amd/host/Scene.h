@@ -72,7 +72,7 @@ FlatScene flattenScene(const std::vector<Object *> &objs, const std::vector<Ligh
 void uploadScene(rt_context *ctx, const FlatScene &s, const std::string &texture_dir, bool commit = true);
 
 // Lazily created process-wide context on HIP device `device` (default: RT_DEVICE env or 0).
-rt_context *defaultContext();
+rt_context *defaultContext(int device = -1);  // device >= 0: that GPU (replaces a context on another one); -1: RT_DEVICE, else 0
 
 struct RenderOptions {
     int spp = 4;        // main.cpp:625
@@ -115,7 +115,7 @@ Camera sampleScene(const std::string &meshDir = "./meshes");         // main.cpp
 Camera bunnyScene(const std::string &meshDir = "./meshes");          // sampleScene minus the spheres
 Camera competitionScene(const std::string &meshDir = "./meshes");    // main.cpp:409-536 minus the missing pietre.obj
 Camera coneScene(const std::string &meshDir = "./meshes");             // Cone test scene (oracle/ref_harness.cpp: cones_scene)
-Camera stressScene(const std::string &meshDir, int replicas);        // competition meshes on a lattice
+Camera stressScene(const std::string &meshDir, int replicas, bool diagonal = false);        // competition meshes on a lattice
 void clearScene();
 // render()/trace_ray() re-upload the globals whenever their fingerprint changes (objects, materials, transformations,
 // lights, ambient_light, texture directory); invalidateScene() forces it for edits the fingerprint cannot see.

@@ -316,7 +316,11 @@ Camera coneScene(const std::string &meshDir) {
 
 // the 16 competition mesh instances replicated on a translation lattice (synthetic, no
 // reference counterpart).  replica r sits at lattice cell (ix, iz) with spacing 3.5 in x and z.
-Camera stressScene(const std::string &meshDir, int replicas) {
+// diagonal: the second stress camera -- low above the ground at the lattice's near corner, looking along its diagonal, so
+// that a ray crosses hundreds of replicas before it leaves the lattice: the node working set of a frame is then the whole
+// tree (GBs, far beyond L2 and the Infinity Cache), which makes this the bandwidth-bound case C5 is meant to be (the first
+// camera looks down on the lattice: 3.5 nodes per ray).
+Camera stressScene(const std::string &meshDir, int replicas, bool diagonal) {
     CompetitionMaterials M;
     std::vector<MeshJob> jobs;
     for (const MeshPlacement &p : kCompetitionMeshes) jobs.push_back({meshDir + "/" + p.file, glm::vec3(p.x, p.y, p.z), &(M.*(p.mat))});
@@ -340,5 +344,10 @@ Camera stressScene(const std::string &meshDir, int replicas) {
     competitionGroundAndLights(M);
     Camera c = competitionCamera();
     c.origin = glm::vec3(-0.45, 2.5, 4.0);  // pulled back and up so the lattice is in view
+    if (diagonal) {
+        c.origin = glm::vec3(1.0f, 0.25f, 3.0f);
+        // looks along (-1, -0.06, -1): rotY(45 deg) turns -z towards -x, a slight pitch down keeps the far replicas in view
+        c.rotation = glm::rotate(glm::mat4(1.0f), 0.7853982f, glm::vec3(0, 1, 0)) * glm::rotate(glm::mat4(1.0f), -0.06f, glm::vec3(1, 0, 0));
+    }
     return c;
 }

@@ -23,7 +23,7 @@ extern "C" {
 
 const char *rth_last_error(void) { return g_err.c_str(); }
 
-// name: "sample" | "bunny" | "competition" | "stress:<replicas>"; asset_dir holds meshes/ and textures/
+// name: "sample" | "bunny" | "competition" | "cones" | "stress:<replicas>" | "stress-diagonal:<replicas>" (second camera); asset_dir holds meshes/ and textures/
 void *rth_scene_create(const char *name, const char *asset_dir) {
     try {
         clearScene();
@@ -34,6 +34,7 @@ void *rth_scene_create(const char *name, const char *asset_dir) {
         else if (n == "competition") hs->camera = competitionScene(meshes);
         else if (n == "cones") hs->camera = coneScene(meshes);
         else if (n.rfind("stress:", 0) == 0) hs->camera = stressScene(meshes, std::atoi(n.c_str() + 7));
+        else if (n.rfind("stress-diagonal:", 0) == 0) hs->camera = stressScene(meshes, std::atoi(n.c_str() + 16), true);
         else throw std::runtime_error("unknown scene '" + n + "'");
         hs->flat = flattenScene(objects, lights, ambient_light);
         hs->textureDir = dir + "/textures";

@@ -210,7 +210,9 @@ class MultiRenderer:
         prim = np.zeros((height, width), np.uint32) if "primid" in want else None
         st = (N.Stats * self.n)()
         self._check(self.lib.rt_multi_render(self._m, C.byref(cam), C.byref(p), _p(rgb8), _p(rgbf), _p(prim), C.cast(st, C.c_void_p)))
-        return dict(rgb8=rgb8, rgbf=rgbf, primid=prim, stats=[x.as_dict() for x in st])
+        t = N.MultiTimings()
+        self._check(self.lib.rt_multi_last_timings(self._m, C.byref(t)))
+        return dict(rgb8=rgb8, rgbf=rgbf, primid=prim, stats=[x.as_dict() for x in st], timings=t.as_dict())
 
     def close(self):
         if getattr(self, "_m", None):

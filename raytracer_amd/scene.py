@@ -99,7 +99,7 @@ class FlatScene:
 
     @classmethod
     def builtin(cls, name, asset_dir=None, lazy=False):
-        """name: 'sample' | 'bunny' | 'competition' | 'cones' | 'stress:<replicas>'"""
+        """name: 'sample' | 'bunny' | 'competition' | 'cones' | 'stress:<replicas>' | 'stress-diagonal:<replicas>'"""
         asset_dir = asset_dir or N.ASSET_DIR
         lib = N.host_lib(lazy=lazy)
         h = lib.rth_scene_create(name.encode(), asset_dir.encode())

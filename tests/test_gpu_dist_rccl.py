@@ -12,11 +12,19 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a TCP port nobody listens on right now (a fixed one collides with a run that is still winding down)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 @pytest.mark.gpu
 def test_bench_under_torchrun_with_rccl_gather():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--master-port", _free_port(), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--scene", "sample", "--width", "320", "--height", "208", "--spp", "4", "--no-cpu", "--no-roofline", "--force-dist"]
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -24,6 +32,8 @@ def test_bench_under_torchrun_with_rccl_gather():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
     assert d["config"]["tiles"] == 20 * 13
+    # where the frame's time went, per rank: share, gather, assembly
+    assert len(d["multi"]["share_ms"]) == 1 and d["multi"]["share_ms"][0] > 0 and d["multi"]["gather_ms_rank0"] >= 0
 
     # the same frame without the collective gives the same ray count (the gather changes nothing but where the tiles end up)
     plain = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--scene", "sample",
@@ -42,7 +52,7 @@ def test_bench_two_ranks_control_flow_on_one_card():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     common = ["--steps", "2", "--warmup", "1", "--scene", "sample", "--width", "320", "--height", "208", "--spp", "4", "--no-cpu"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29543", os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-gloo"] + common
+           "--master-port", _free_port(), os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-gloo"] + common
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

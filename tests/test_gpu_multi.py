@@ -55,3 +55,25 @@ def test_ranks_sharing_one_gpu_equal_rt_render(ranks):
     out8 = m.render(w, h, spp=4, max_depth=3, want=("rgb8",))  # without the float image / prim ids
     assert np.array_equal(out8["rgb8"], ref["rgb8"])
     m.close()
+
+
+def test_timings_and_the_timed_multi_abi_mode_of_bench():
+    """rt_multi_last_timings tells where a frame's wall time went (per-rank share, exchange, assembly, read-back), and
+    bench.py --multi-abi times the path a C++ host links -- rehearsed with two ranks on the one card."""
+    import json, os, subprocess, sys
+    from raytracer_amd.renderer import MultiRenderer
+    scene = get_scene("competition", False)
+    m = MultiRenderer([0, 0]).set_scene(scene)
+    for _ in range(2):  # (the worker threads of the rt_multi outlive a frame)
+        out = m.render(200, 120, spp=4, max_depth=3, want=("rgb8",))
+    t = out["timings"]
+    assert t["ms_share_max"] >= t["ms_share_min"] > 0 and t["ms_render_wall"] >= t["ms_share_max"] * 0.5
+    assert t["ms_exchange"] >= 0 and t["ms_assemble"] > 0 and t["ms_readback"] > 0
+    m.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--multi-abi", "--multi-devices", "0,0", "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--scene", "sample", "--width", "320", "--height", "208", "--spp", "4"],
+                         cwd=repo, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    d = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["multi"]["share_ms"]) == 2 and "copy" in d["multi"]["path"]

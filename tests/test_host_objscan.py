@@ -38,6 +38,16 @@ CASES = ["0", "-0", "0.0", "-0.000", "1", "-1", "1.5", "-.5", "5.", ".", "-", ""
          "1.5e0010", "1e00000000000000000005", "1e99999999999", "-1e-99999999999", "1.e3", ".e3", "1.2.3", "1..2"]
 
 
+def test_dangling_exponent_follows_strtof(scan):
+    """A malformed number with a dangling exponent: glibc's scanf("%f") consumes the 'e' and fails the conversion (target left
+    stale), strtof converts the mantissa and stops in front of the 'e'.  The scanner follows strtof -- a deliberate, documented
+    difference from the reference's sscanf on input that none of its assets contains (MeshLoader.h)."""
+    for text, value, consumed in (("1e", 1.0, 1), ("1.5e+ 2", 1.5, 3), ("-2.25e-x", -2.25, 5), ("3E", 3.0, 1)):
+        v, n, ref, rn, _ = scan(text)
+        assert (v, n) == (ref, rn)                                    # the same as libc's strtof ...
+        assert n == consumed and struct.unpack("<f", struct.pack("<I", v))[0] == value  # ... which converts the mantissa alone
+
+
 def test_scan_float_cases(scan):
     for t in CASES:
         v, n, ref, rn, _ = scan(t)
