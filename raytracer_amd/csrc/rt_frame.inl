@@ -541,10 +541,10 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         TailProf tp;
         tp.on = getenv("RT_TAILPROF") != nullptr;
         if (tp.on) {
-            const size_t slots = 8 * (3 * (pl.nchunks + 16) + 8);
+            const size_t slots = 16 * (3 * (pl.nchunks + 16) + 8);
             if (tp.buf.alloc(slots)) return 1;
             std::vector<unsigned long long> init(slots);
-            for (size_t k = 0; k < slots; k++) init[k] = (k & 7) < 2 ? ~0ull : 0ull;
+            for (size_t k = 0; k < slots; k++) init[k] = ((k & 15) < 2 || (k & 15) == 12 || (k & 15) == 13) ? ~0ull : 0ull;
             HIPOK(hipMemcpy(tp.buf.p, init.data(), slots * 8, hipMemcpyHostToDevice));
         }
         if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, per_tile, d_rgb8, d_rgbf, d_primid, stats_on, fuse, kt, &launches, &tp)) return 1;
@@ -554,14 +554,19 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         HIPOK(hipStreamSynchronize(stream));
         HIPOK(hipGetLastError());
         if (tp.on) {
-            std::vector<unsigned long long> h(8 * tp.recs.size());
+            std::vector<unsigned long long> h(16 * tp.recs.size());
             HIPOK(hipMemcpy(h.data(), tp.buf.p, h.size() * 8, hipMemcpyDeviceToHost));
             double dur[8] = {0}, tail[8] = {0}, ramp_idle[8] = {0}, ramp[8] = {0}, mtail[8] = {0}, lstart[8] = {0};
             int cnt[8] = {0};
             for (size_t k = 0; k < tp.recs.size(); k++) {
-                const unsigned long long *r = h.data() + 8 * k;
+                const unsigned long long *r = h.data() + 16 * k;
                 if (r[2] == 0) continue;
                 const int c = tp.recs[k].cls;
+                if (c == 6 && getenv("RT_TAILPROF_LAUNCHES"))  // per fused launch: when the first / mean / last wave leaves each phase, in us after the first wave's start
+                    std::fprintf(stderr, "[rt]   k_trace launch %zu: shadow phase left at %.0f / %.0f / %.0f us, bounce phase at %.0f / %.0f / %.0f, launch ends at %.0f / %.0f / %.0f\n", k,
+                                 (double)(r[12] - r[0]) / 100.0, ((double)r[9] / tp.recs[k].waves - (double)r[0]) / 100.0, (double)(r[8] - r[0]) / 100.0,
+                                 (double)(r[13] - r[0]) / 100.0, ((double)r[11] / tp.recs[k].waves - (double)r[0]) / 100.0, (double)(r[10] - r[0]) / 100.0,
+                                 (double)(r[1] - r[0]) / 100.0, ((double)r[5] / tp.recs[k].waves - (double)r[0]) / 100.0, (double)(r[2] - r[0]) / 100.0);
                 const double d = (double)(r[2] - r[0]) / 100.0;  // us
                 dur[c] += d;
                 tail[c] += (double)(r[2] - r[1]) / 100.0;

@@ -37,13 +37,24 @@ RT_DEV unsigned long long rtTailBegin(const RtQueues &q) { return q.tailprof ? w
 RT_DEV void rtTailEnd(const RtQueues &q, unsigned long long t0) {
     if (q.tailprof && laneId() == 0) {
         const unsigned long long t1 = wall_clock64();
-        unsigned long long *p = q.tailprof + 8ull * q.launch_id;
+        unsigned long long *p = q.tailprof + 16ull * q.launch_id;
         atomicMin(p + 0, t0);
         atomicMin(p + 1, t1);
         atomicMax(p + 2, t1);
         atomicAdd(p + 3, t1 - t0);
         atomicMax(p + 4, t0);
         atomicAdd(p + 5, t1);
+    }
+}
+
+// ... and when they leave a phase of the fused traversal launch (k: 0 = the shadow rays, 1 = the bounce rays)
+RT_DEV void rtTailMark(const RtQueues &q, int k) {
+    if (q.tailprof && laneId() == 0) {
+        const unsigned long long t = wall_clock64();
+        unsigned long long *p = q.tailprof + 16ull * q.launch_id;
+        atomicMax(p + 8 + 2 * k, t);
+        atomicAdd(p + 9 + 2 * k, t);
+        atomicMin(p + 12 + k, t);
     }
 }
 
@@ -542,15 +553,92 @@ RT_DEV void rtShadowRay(const RtSceneDev &sc, float4 A, uint32_t light, RtRay &r
 // barrier): the phases of the fused kernel (k_trace) share it, and a wave moves from one phase to the next on its own.
 struct RtTraceLds {
     RtStack stk;
-    RtLdsWord *age;
+    RtLdsWord *age;   // 64 words per wave: any-hit walks keep the lanes' ages here, closest-hit walks the order of their batch (256 bytes)
+    RtLdsWord *aux;   // 64 words per wave: bin counters of rtSortBatch
     RtAnalytic an;
 };
 RT_DEV RtTraceLds rtTraceSetup(const RtSceneDev &sc, const RtQueues &q, uint32_t *lds, int stack_entries) {
     RtTraceLds t;
     t.stk = rtMakeStack(lds, q.spill, stack_entries);
-    t.age = (RtLdsWord *)(lds + stack_entries * RT_BLOCK + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
-    t.an = stageAnalytic(sc, lds + (stack_entries + 1) * RT_BLOCK);
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+    t.age = (RtLdsWord *)(lds + stack_entries * RT_BLOCK + wave0);
+    t.aux = (RtLdsWord *)(lds + (stack_entries + 1) * RT_BLOCK + wave0);
+    t.an = stageAnalytic(sc, lds + (stack_entries + 2) * RT_BLOCK);
     return t;
+}
+
+// Order of consumption inside a batch of closest-hit rays.  A wave is as slow as its slowest lane, and how long a ray walks
+// depends on where it goes: the <= 256 rays of a batch (consecutive queue entries, i.e. rays that left neighbouring hits) are
+// consumed grouped by KIND (the refraction ray of a reflection / refraction pair dives into the object it entered, the
+// reflection ray crosses the scene) and by the OCTANT of their direction, so that the rays a wave holds at any time walk
+// alike.  Order is free -- results go to the ray's own slot.  A counting sort through LDS: one returning LDS add per ray
+// gives its rank inside its bin (64 bins), a wave scan the bins' first slots; perm[k] (a byte) = the batch entry consumed k-th.
+// All 64 lanes call this together; len <= 256.
+#ifndef RT_SORT_BATCH
+#define RT_SORT_BATCH 1
+#endif
+typedef __attribute__((address_space(3))) uint8_t RtLdsByte;
+RT_DEV void rtSortBatch(const RtQueues &q, int buf, uint32_t pool_base, uint32_t len, RtLdsWord *permw, RtLdsWord *bins) {
+    const uint32_t lane = laneId();
+    RtLdsByte *perm = (RtLdsByte *)permw;
+    bins[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t kr[4];        // bin | rank inside the bin << 8, per sub-block of 64 entries
+    uint32_t carry = 0u;   // the entry in front of the sub-block's first is a reflection ray with a refraction sibling
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t idx = (uint32_t)k * 64u + lane;
+        const bool valid = idx < len;
+        float4 B = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(RT_FLAG_INVALID));
+        if (valid) B = q.rayB[buf][pool_base + idx];
+        const uint32_t tag = __float_as_uint(B.w);
+        const uint32_t sib = (tag & RT_FLAG_HAS_REFR_SIBLING) ? 1u : 0u;
+        uint32_t prev = __shfl_up(sib, 1);
+        if (lane == 0u) prev = carry;
+        carry = __builtin_amdgcn_readlane(sib, 63);
+        const uint32_t oct = (__float_as_uint(B.x) >> 31) | ((__float_as_uint(B.y) >> 31) << 1) | ((__float_as_uint(B.z) >> 31) << 2);
+#ifndef RT_SORT_KEY
+#define RT_SORT_KEY 0
+#endif
+#if RT_SORT_KEY == 0
+        const uint32_t bin = (tag & RT_FLAG_INVALID) ? 63u : (oct | (prev << 3));
+#elif RT_SORT_KEY == 1
+        const uint32_t bin = (tag & RT_FLAG_INVALID) ? 63u : oct;
+#elif RT_SORT_KEY == 2
+        const float ax = fabsf(B.x), ay = fabsf(B.y), az = fabsf(B.z);
+        const uint32_t major = ax >= ay && ax >= az ? 0u : (ay >= az ? 1u : 2u);
+        const uint32_t bin = (tag & RT_FLAG_INVALID) ? 63u : (major | (oct << 2) | (prev << 5));
+#elif RT_SORT_KEY == 3
+        const uint32_t lvl = min((tag >> q.level_shift) & q.level_mask, 3u);
+        const uint32_t bin = (tag & RT_FLAG_INVALID) ? 63u : (oct | (prev << 3) | (lvl << 4));
+#elif RT_SORT_KEY == 4
+        const uint32_t bin = (tag & RT_FLAG_INVALID) ? 63u : prev;
+#endif
+        uint32_t rank = 0u;
+        if (valid) rank = __hip_atomic_fetch_add(bins + bin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        kr[k] = bin | (rank << 8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t cnt = bins[lane];
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bins[lane] = incl - cnt;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t idx = (uint32_t)k * 64u + lane;
+        if (idx < len) perm[bins[kr[k] & 255u] + (kr[k] >> 8)] = (uint8_t)idx;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // L0: level-0 shadow results are stored, not added (RtQueues::occ0) -- an instance of its own, so that the usual one keeps
@@ -589,6 +677,8 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     bool occl = false;                                     // SPLIT: the finished item found a hit
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;  // wave-uniform
+    constexpr bool SORTED = RT_SORT_BATCH && !ANY && MODE == RT_MODE_QUEUE && batch <= 256u;  // rtSortBatch
+    bool sorted = false;                                   // wave-uniform: the current batch has an order in LDS
     uint32_t part_seen = 0;                                // how far the current part had got at this wave's last fetch
 #ifndef RT_TAIL_FACTOR
 #define RT_TAIL_FACTOR 1u
@@ -708,6 +798,10 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     pool_end = min(pool_next + want, hi);
                     pool_base = pool_next;
                     part_seen = base + want;
+                    if (SORTED) {
+                        sorted = pool_end - pool_base > 64u;  // (one generation of rays is taken as it comes)
+                        if (sorted) rtSortBatch(q, buf, pool_base, pool_end - pool_base, tl.age, tl.aux);
+                    }
                 } else {  // this part is used up: on to the next
                     part = part + 1 == PARTS ? 0u : part + 1;
                     parts_done++;
@@ -746,7 +840,9 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     // even entries first, then the odd ones (order is free: results go to the ray's own slot): 39 -> 42 of
                     // 64 lanes per node phase, k_closest 179 -> 161 ms on the 4K frame.  (Unpaired rays shift the parity;
                     // that only weakens the separation.)
-                    if (!ANY) {
+                    if (SORTED) {  // grouped by kind and direction octant (rtSortBatch)
+                        if (sorted) pos = pool_base + ((const RtLdsByte *)tl.age)[pos - pool_base];
+                    } else if (!ANY) {
                         const uint32_t off = pos - pool_base, len = pool_end - pool_base, half = (len + 1u) >> 1;
                         pos = pool_base + (off < half ? 2u * off : 2u * (off - half) + 1u);
                     }
@@ -1114,9 +1210,11 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_trace(RtSceneDev sc, uint32_t r
         if (par_closest >= 0 && !RT_FUSED_TAIL) traceQueue<true, STATS, RT_MODE_QUEUE, L0, false>(sc, root_ref, q, tl, par_any, 0u, -1, budget);
         else traceQueue<true, STATS, RT_MODE_QUEUE, L0, true>(sc, root_ref, q, tl, par_any, 0u, -1, budget);
     }
+    rtTailMark(q, 0);
     if (par_closest >= 0) {
         if (packets && !RT_FUSED_TAIL) traceQueue<false, STATS, RT_MODE_QUEUE, false, false>(sc, root_ref, q, tl, par_closest, first, -1, 0u);
         else traceQueue<false, STATS, RT_MODE_QUEUE, false, true>(sc, root_ref, q, tl, par_closest, first, -1, 0u);
+        rtTailMark(q, 1);
         if (packets) packetQueue<(STATS != 0)>(sc, root_ref, q, tl, par_closest);
     }
     rtTailEnd(q, tp0);
@@ -1778,7 +1876,7 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 }
 // (stats: 0 = plain, 1 = counters, 2 = counters + wave-time profile)
 #define RT_BY_STATS(CALL) do { if (stats >= 2) { CALL(2); } else if (stats == 1) { CALL(1); } else { CALL(0); } } while (0)
-static inline size_t traceLds(const RtLaunchCfg &cfg) { return (size_t)(cfg.stack_entries + 1) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes; }
+static inline size_t traceLds(const RtLaunchCfg &cfg) { return (size_t)(cfg.stack_entries + 2) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes; }
 static inline uint32_t splitBudget(const RtLaunchCfg &cfg, const RtQueues &q) { return q.split_cap ? (uint32_t)cfg.split_budget : 0u; }
 // The fused traversal launch of an iteration (k_trace): shadow queue `par_any`, bounce rays [first, n) of ray queue
 // `par_closest`, its primary rays [0, q.prim_n) as packets.  A parity < 0 skips the phase.

@@ -193,7 +193,7 @@ struct RtQueues {
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap, general_cap;
     // RT_TAILPROF (diagnosis): per launch {first wave start, first wave end, last wave end, sum of wave lifetimes, last wave
-    // start, sum of wave ends} in 100 MHz ticks, at tailprof[8 * launch_id]; null = off
+    // start, sum of wave ends} in 100 MHz ticks, at tailprof[16 * launch_id] (+ the phase marks of k_trace at words 8..13); null = off
     unsigned long long *tailprof;
     uint32_t launch_id;
     // this iteration (set by the host per launch): entries [0, prim_n) of the current ray queue are the primary rays of the
