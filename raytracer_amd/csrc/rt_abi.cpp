@@ -518,7 +518,7 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     ctx->dev.occluder_cache = 1;  // RT_OCCLUDER_CACHE=0: shadow queries independent of scheduling down to the last float bit
     if (const char *e = getenv("RT_OCCLUDER_CACHE")) ctx->dev.occluder_cache = atoi(e) != 0;
     ctx->cfg.analytic_bytes = (int)(img.units.size() * sizeof(RtSphere) + src->planes.size() * sizeof(RtPlane));
-    const int lds_per_block = (entries + 2) * 256 * 4 + ctx->cfg.analytic_bytes;  // stack rows + the age row + the aux row + analytic primitives
+    const int lds_per_block = (entries + RT_TRACE_LDS_ROWS) * 256 * 4 + ctx->cfg.analytic_bytes;  // stack rows + the age row + the aux row + analytic primitives
     if (const char *e = getenv("RT_SPLIT_BUDGET")) {  // 0 = never split a shadow walk; rounded down to a power of two
         int b = std::max(0, atoi(e)), p2 = 0;
         while (b > 1) { b >>= 1; p2++; }

@@ -541,11 +541,9 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         TailProf tp;
         tp.on = getenv("RT_TAILPROF") != nullptr;
         if (tp.on) {
-            const size_t slots = 16 * (3 * (pl.nchunks + 16) + 8);
+            const size_t slots = (size_t)RT_TAIL_WAVES * 4 * (3 * (pl.nchunks + 16) + 8);
             if (tp.buf.alloc(slots)) return 1;
-            std::vector<unsigned long long> init(slots);
-            for (size_t k = 0; k < slots; k++) init[k] = ((k & 15) < 2 || (k & 15) == 12 || (k & 15) == 13) ? ~0ull : 0ull;
-            HIPOK(hipMemcpy(tp.buf.p, init.data(), slots * 8, hipMemcpyHostToDevice));
+            HIPOK(hipMemset(tp.buf.p, 0, slots * sizeof(unsigned long long)));
         }
         if (enqueueFrame(ctx, cfg, f, pl, q, p->max_depth, (size_t)n_local, per_tile, d_rgb8, d_rgbf, d_primid, stats_on, fuse, kt, &launches, &tp)) return 1;
         for (int l = 0; l < pl.lanes; l++)
@@ -553,35 +551,48 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         HIPOK(hipEventRecord(ev.b, stream));
         HIPOK(hipStreamSynchronize(stream));
         HIPOK(hipGetLastError());
-        if (tp.on) {
-            std::vector<unsigned long long> h(16 * tp.recs.size());
+        if (tp.on) {  // per launch: when the first / mean / last wave left each phase and ended, in us after the first wave's start
+            std::vector<unsigned long long> h((size_t)RT_TAIL_WAVES * 4 * tp.recs.size());
             HIPOK(hipMemcpy(h.data(), tp.buf.p, h.size() * 8, hipMemcpyDeviceToHost));
-            double dur[8] = {0}, tail[8] = {0}, ramp_idle[8] = {0}, ramp[8] = {0}, mtail[8] = {0}, lstart[8] = {0};
-            int cnt[8] = {0};
+            struct Acc { double dur = 0, idle = 0, first_end = 0; int n = 0; } acc[8];
             for (size_t k = 0; k < tp.recs.size(); k++) {
-                const unsigned long long *r = h.data() + 16 * k;
-                if (r[2] == 0) continue;
-                const int c = tp.recs[k].cls;
-                if (c == 6 && getenv("RT_TAILPROF_LAUNCHES"))  // per fused launch: when the first / mean / last wave leaves each phase, in us after the first wave's start
-                    std::fprintf(stderr, "[rt]   k_trace launch %zu: shadow phase left at %.0f / %.0f / %.0f us, bounce phase at %.0f / %.0f / %.0f, launch ends at %.0f / %.0f / %.0f\n", k,
-                                 (double)(r[12] - r[0]) / 100.0, ((double)r[9] / tp.recs[k].waves - (double)r[0]) / 100.0, (double)(r[8] - r[0]) / 100.0,
-                                 (double)(r[13] - r[0]) / 100.0, ((double)r[11] / tp.recs[k].waves - (double)r[0]) / 100.0, (double)(r[10] - r[0]) / 100.0,
-                                 (double)(r[1] - r[0]) / 100.0, ((double)r[5] / tp.recs[k].waves - (double)r[0]) / 100.0, (double)(r[2] - r[0]) / 100.0);
-                const double d = (double)(r[2] - r[0]) / 100.0;  // us
-                dur[c] += d;
-                tail[c] += (double)(r[2] - r[1]) / 100.0;
-                ramp_idle[c] += d - (double)r[3] / 100.0 / tp.recs[k].waves;  // launch duration minus the mean wave lifetime
-                const double mean_end = (double)r[5] / tp.recs[k].waves, mean_life = (double)r[3] / tp.recs[k].waves;
-                ramp[c] += (mean_end - mean_life - (double)r[0]) / 100.0;   // mean wave start after the first wave's
-                mtail[c] += ((double)r[2] - mean_end) / 100.0;               // mean wave end before the last wave's
-                lstart[c] += (double)(r[4] - r[0]) / 100.0;                  // last wave start after the first
-                cnt[c]++;
+                const unsigned long long *r = h.data() + (size_t)RT_TAIL_WAVES * 4 * k;
+                unsigned long long t0 = ~0ull;
+                size_t waves = 0;
+                for (size_t w = 0; w < RT_TAIL_WAVES; w++)
+                    if (r[4 * w + 3]) {
+                        t0 = std::min(t0, r[4 * w]);
+                        waves++;
+                    }
+                if (!waves) continue;
+                double mn[4], mx[4], sum[4];
+                size_t cnt[4];
+                for (int c = 0; c < 4; c++) { mn[c] = 1e30; mx[c] = 0; sum[c] = 0; cnt[c] = 0; }
+                for (size_t w = 0; w < RT_TAIL_WAVES; w++) {
+                    if (!r[4 * w + 3]) continue;
+                    for (int c = 0; c < 4; c++) {
+                        if (!r[4 * w + c]) continue;
+                        const double t = (double)(r[4 * w + c] - t0) / 100.0;
+                        mn[c] = std::min(mn[c], t); mx[c] = std::max(mx[c], t); sum[c] += t; cnt[c]++;
+                    }
+                }
+                const int cls = tp.recs[k].cls;
+                acc[cls].dur += mx[3];
+                acc[cls].idle += mx[3] - sum[3] / (double)waves + sum[0] / (double)waves;
+                acc[cls].first_end += mx[3] - mn[3];
+                acc[cls].n++;
+                if (getenv("RT_TAILPROF_LAUNCHES")) {
+                    std::fprintf(stderr, "[rt]   launch %zu (class %d, %zu waves): last start %.0f us", k, cls, waves, mx[0]);
+                    if (cnt[1]) std::fprintf(stderr, "; shadow phase left at %.0f / %.0f / %.0f", mn[1], sum[1] / cnt[1], mx[1]);
+                    if (cnt[2]) std::fprintf(stderr, "; bounce phase left at %.0f / %.0f / %.0f", mn[2], sum[2] / cnt[2], mx[2]);
+                    std::fprintf(stderr, "; ends at %.0f / %.0f / %.0f\n", mn[3], sum[3] / cnt[3], mx[3]);
+                }
             }
             for (int c = 0; c < 8; c++)
-                if (cnt[c])
+                if (acc[c].n)
                     std::fprintf(stderr, "[rt] tailprof class %d: %d launches, mean duration %.0f us, first wave done %.0f us before the last, "
-                                 "mean wave absent for %.0f us of a launch: starts %.0f us after the first (last start %.0f us), ends %.0f us before the last\n",
-                                 c, cnt[c], dur[c] / cnt[c], tail[c] / cnt[c], ramp_idle[c] / cnt[c], ramp[c] / cnt[c], lstart[c] / cnt[c], mtail[c] / cnt[c]);
+                                 "mean wave absent (late start + early end) for %.0f us of a launch\n",
+                                 c, acc[c].n, acc[c].dur / acc[c].n, acc[c].first_end / acc[c].n, acc[c].idle / acc[c].n);
             tp.buf.release();
         }
         st->chunks += pl.nchunks;

@@ -32,29 +32,21 @@ RT_DEV uint32_t waveReserve(uint32_t *counter, uint32_t total) {
     return __builtin_amdgcn_readfirstlane(base);
 }
 
-// RT_TAILPROF: when the waves of a launch start and end (RtQueues::tailprof)
-RT_DEV unsigned long long rtTailBegin(const RtQueues &q) { return q.tailprof ? wall_clock64() : 0ull; }
-RT_DEV void rtTailEnd(const RtQueues &q, unsigned long long t0) {
-    if (q.tailprof && laneId() == 0) {
-        const unsigned long long t1 = wall_clock64();
-        unsigned long long *p = q.tailprof + 16ull * q.launch_id;
-        atomicMin(p + 0, t0);
-        atomicMin(p + 1, t1);
-        atomicMax(p + 2, t1);
-        atomicAdd(p + 3, t1 - t0);
-        atomicMax(p + 4, t0);
-        atomicAdd(p + 5, t1);
-    }
+// RT_TAILPROF: when the waves of a launch start, leave a phase and end (RtQueues::tailprof).  Every wave writes its own four
+// words [t0, left phase 0, left phase 1, t1] (100 MHz ticks) -- nothing shared: a probe that folded its times into one
+// line per launch with atomics queued 6 x 8192 of them on one address at the end of a launch, and measured mostly itself.
+RT_DEV unsigned long long *rtTailSlot(const RtQueues &q) {
+    return q.tailprof + ((size_t)q.launch_id * RT_TAIL_WAVES + (size_t)blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6)) * 4;
 }
-
-// ... and when they leave a phase of the fused traversal launch (k: 0 = the shadow rays, 1 = the bounce rays)
-RT_DEV void rtTailMark(const RtQueues &q, int k) {
-    if (q.tailprof && laneId() == 0) {
-        const unsigned long long t = wall_clock64();
-        unsigned long long *p = q.tailprof + 16ull * q.launch_id;
-        atomicMax(p + 8 + 2 * k, t);
-        atomicAdd(p + 9 + 2 * k, t);
-        atomicMin(p + 12 + k, t);
+RT_DEV unsigned long long rtTailBegin(const RtQueues &q) { return q.tailprof ? wall_clock64() : 0ull; }
+RT_DEV void rtTailMark(const RtQueues &q, int k) {  // k: 0 = the shadow rays, 1 = the bounce rays of the fused traversal launch
+    if (q.tailprof && laneId() == 0 && blockIdx.x * (RT_BLOCK / 64) < RT_TAIL_WAVES) rtTailSlot(q)[1 + k] = wall_clock64();
+}
+RT_DEV void rtTailEnd(const RtQueues &q, unsigned long long t0) {
+    if (q.tailprof && laneId() == 0 && blockIdx.x * (RT_BLOCK / 64) < RT_TAIL_WAVES) {
+        unsigned long long *p = rtTailSlot(q);
+        p[0] = t0;
+        p[3] = wall_clock64();
     }
 }
 
@@ -563,7 +555,7 @@ RT_DEV RtTraceLds rtTraceSetup(const RtSceneDev &sc, const RtQueues &q, uint32_t
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     t.age = (RtLdsWord *)(lds + stack_entries * RT_BLOCK + wave0);
     t.aux = (RtLdsWord *)(lds + (stack_entries + 1) * RT_BLOCK + wave0);
-    t.an = stageAnalytic(sc, lds + (stack_entries + 2) * RT_BLOCK);
+    t.an = stageAnalytic(sc, lds + (stack_entries + RT_TRACE_LDS_ROWS) * RT_BLOCK);
     return t;
 }
 
@@ -1734,8 +1726,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(RtFrameDev f, RtQueues q, 
         const uint32_t m = pm & 255u;
         const uint32_t px = compact1By1(m), py = compact1By1(m >> 1);
         V3 sum = v3s(0.0f);
-        for (int s = 0; s < f.spp; s++) {
-            const long long *a = q.accum + 3ull * ((size_t)sample0 + (size_t)pm * f.spp + s);  // sample0: the chunk's slot in the accumulator ring
+        const long long *a0 = q.accum + 3ull * ((size_t)sample0 + (size_t)pm * f.spp);  // sample0: the chunk's slot in the accumulator ring
+        int s = 0;
+        // A lane's samples are 24 * spp contiguous bytes, 1536 B away from its neighbour's at 64 spp: fetched 8 bytes at a time
+        // the 64 lines a wave touches per load fall out of the L1 before their other samples are read (counter traffic 2.8 x
+        // the buffer).  Four samples = six 16-byte loads issued together use every line while it is there.  The samples are
+        // still added one after the other, in order, as the reference's loop does (main.cpp:646): same float bits.
+        if ((f.spp & 3) == 0) {
+            for (; s < f.spp; s += 4) {
+                const longlong2 *a = reinterpret_cast<const longlong2 *>(a0 + 3 * s);
+                const longlong2 v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = a[4], v5 = a[5];
+                sum.x += gclamp(rtFromFixed(v0.x), 0.0f, 1.0f); sum.y += gclamp(rtFromFixed(v0.y), 0.0f, 1.0f); sum.z += gclamp(rtFromFixed(v1.x), 0.0f, 1.0f);
+                sum.x += gclamp(rtFromFixed(v1.y), 0.0f, 1.0f); sum.y += gclamp(rtFromFixed(v2.x), 0.0f, 1.0f); sum.z += gclamp(rtFromFixed(v2.y), 0.0f, 1.0f);
+                sum.x += gclamp(rtFromFixed(v3.x), 0.0f, 1.0f); sum.y += gclamp(rtFromFixed(v3.y), 0.0f, 1.0f); sum.z += gclamp(rtFromFixed(v4.x), 0.0f, 1.0f);
+                sum.x += gclamp(rtFromFixed(v4.y), 0.0f, 1.0f); sum.y += gclamp(rtFromFixed(v5.x), 0.0f, 1.0f); sum.z += gclamp(rtFromFixed(v5.y), 0.0f, 1.0f);
+            }
+        }
+        for (; s < f.spp; s++) {
+            const long long *a = a0 + 3 * s;
             sum.x += gclamp(rtFromFixed(a[0]), 0.0f, 1.0f);
             sum.y += gclamp(rtFromFixed(a[1]), 0.0f, 1.0f);
             sum.z += gclamp(rtFromFixed(a[2]), 0.0f, 1.0f);
@@ -1876,7 +1884,7 @@ void rtLaunchGenPrimary(const RtLaunchCfg &cfg, const RtFrameDev &f, const RtQue
 }
 // (stats: 0 = plain, 1 = counters, 2 = counters + wave-time profile)
 #define RT_BY_STATS(CALL) do { if (stats >= 2) { CALL(2); } else if (stats == 1) { CALL(1); } else { CALL(0); } } while (0)
-static inline size_t traceLds(const RtLaunchCfg &cfg) { return (size_t)(cfg.stack_entries + 2) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes; }
+static inline size_t traceLds(const RtLaunchCfg &cfg) { return (size_t)(cfg.stack_entries + RT_TRACE_LDS_ROWS) * RT_BLOCK * sizeof(uint32_t) + cfg.analytic_bytes; }
 static inline uint32_t splitBudget(const RtLaunchCfg &cfg, const RtQueues &q) { return q.split_cap ? (uint32_t)cfg.split_budget : 0u; }
 // The fused traversal launch of an iteration (k_trace): shadow queue `par_any`, bounce rays [first, n) of ray queue
 // `par_closest`, its primary rays [0, q.prim_n) as packets.  A parity < 0 skips the phase.

@@ -168,6 +168,8 @@ struct RtFrameDev {
 #ifndef RT_SHADE_SEGMENT
 #define RT_SHADE_SEGMENT 1024u                // consecutive queue entries a k_shade wave shades before it jumps
 #endif
+#define RT_TRACE_LDS_ROWS 2                  // LDS rows of 256 words behind a traversal block's stack rows: ages / batch order, sort bins
+#define RT_TAIL_WAVES 8192                   // waves of a launch that RT_TAILPROF records
 #define RT_BLOCK 256                         // threads per block of every kernel
 #define RT_FLAG_INVALID 0x80000000u           // slot of a pixel outside the image or unused slab slot: traced as a miss, never shaded
 
@@ -192,8 +194,8 @@ struct RtQueues {
     uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap, general_cap;
-    // RT_TAILPROF (diagnosis): per launch {first wave start, first wave end, last wave end, sum of wave lifetimes, last wave
-    // start, sum of wave ends} in 100 MHz ticks, at tailprof[16 * launch_id] (+ the phase marks of k_trace at words 8..13); null = off
+    // RT_TAILPROF (diagnosis): per launch and wave {start, left phase 0, left phase 1, end} in 100 MHz ticks, at
+    // tailprof[(launch_id * RT_TAIL_WAVES + wave) * 4]; null = off
     unsigned long long *tailprof;
     uint32_t launch_id;
     // this iteration (set by the host per launch): entries [0, prim_n) of the current ray queue are the primary rays of the
