@@ -310,6 +310,13 @@ int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out);
  * (64-byte 4-wide quantised nodes, layout in DESIGN.md), tri_order[n_triangles] = global triangle index held by
  * BVH slot i.  Pass NULL to query sizes only. */
 int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order);
+/* ... and what a walk over it needs besides: the root's reference (node 0, or a leaf reference for a tree of <= 4 triangles),
+ * the slab test's error-bound scale (max |coordinate| of any node box), the deepest traversal stack and how many of its
+ * entries live in LDS.  tests/test_gpu_counters.py walks the tree on the CPU with them (oracle: ro_walk_counts) and
+ * compares node steps / triangle tests with rt_trace_batch's rt_stats.nodes_visited / tris_tested (the
+ * in-kernel counters that the roofline's flops rest on).  No counterpart in the reference (its tree is per mesh,
+ * MeshLoader.h:211-285). */
+int rt_get_bvh_info(rt_context *ctx, uint32_t *root_ref, float *bound, int32_t *max_stack, int32_t *lds_stack_entries);
 
 /* Host-only self check of the BVH builder (no GPU, no context; used by the CPU tests): builds the tree of the given
  * triangles with `threads` host threads (0 = default), returns the node count, a hash of nodes + triangle order (equal

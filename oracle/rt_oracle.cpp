@@ -946,6 +946,112 @@ static void orderRef(const Mesh &m, int node, uint32_t &next, uint32_t *rank) {
     orderRef(m, n.right, next, rank);
 }
 
+// The KERNEL's closest-hit walk restated on the CPU, for the counter identity of SURVEY.md 8(d): the committed tree as
+// rt_get_bvh hands it over (64-byte 4-wide nodes with 8-bit child boxes, rt_types.h: RtNode4; leaf reference =
+// 0x80000000 | (count - 1) << 28 | (n_nodes + first slot); tri_order[slot] = global triangle) is walked for one ray at a
+// time with the traversal kernel's own arithmetic and order (raytracer_amd/csrc/rt_kernels.hip: rtInitWalk, rtNodeStep,
+// rtTriStep, rtPostponeLeaf and the phase rule of traceQueue for a wave whose lanes all hold the same ray: a node step
+// whenever the lane stands at a node, else a triangle step), counting node steps and triangle tests.  No analytic
+// primitives (the test scene has none).  out_slot = BVH slot of the closest triangle or -1.
+int ro_walk_counts(const ro_scene *rs, uint32_t root_ref, float bound, int64_t n_nodes, const uint32_t *nodes, const uint32_t *tri_order,
+                   const int32_t *tri_object, const uint32_t *rank, int64_t n_rays, const float *rays, uint64_t *out_nodes,
+                   uint64_t *out_tris, int64_t *out_slot) {
+    const Scene &s = rs->s;
+    const uint32_t LEAF = 0x80000000u, DONE = 0xFFFFFFFFu, MASK = 0x0FFFFFFFu, MISS = 0xFFFFFFFFu;
+    auto safeInv = [](float d) {
+        float inv = 1.0f / d;
+        const float cap = 1e30f;
+        if (!(std::fabs(inv) <= cap)) inv = std::signbit(d) ? -cap : cap;
+        return inv;
+    };
+    auto asF = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    auto asU = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto ub = [](uint32_t v, int c) { return (float)((v >> (8 * c)) & 0xFFu); };
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n_rays; i++) {
+        const V3 o = v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), d = v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+        const V3 inv = v3(safeInv(d.x), safeInv(d.y), safeInv(d.z));
+        const V3 oi = v3(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+        const float u = 4.76837158e-07f;
+        const V3 err = v3((std::fabs(oi.x) + bound * std::fabs(inv.x)) * u, (std::fabs(oi.y) + bound * std::fabs(inv.y)) * u,
+                          (std::fabs(oi.z) + bound * std::fabs(inv.z)) * u);
+        const V3 oiN = oi + err, oiF = oi - err;
+        std::vector<uint32_t> stack;
+        uint32_t cur = s.tris.empty() ? DONE : root_ref, pend = DONE;
+        float best_t = INFINITY;
+        uint32_t best_id = MISS, best_rank = 0;
+        int best_obj = 0x7FFFFFFF;
+        uint64_t nn = 0, nt = 0;
+        for (;;) {
+            if (pend == DONE && (cur & LEAF) && cur != DONE) {  // rtPostponeLeaf
+                pend = cur;
+                if (stack.empty()) cur = DONE; else { cur = stack.back(); stack.pop_back(); }
+            }
+            if (!(cur & LEAF)) {  // node step
+                nn++;
+                const uint32_t *q = nodes + 16 * (size_t)(cur & MASK);
+                const float org[3] = {asF(q[0]), asF(q[1]), asF(q[2])};
+                const float mx = asF(q[3]) * inv.x, my = asF(q[14]) * inv.y, mz = asF(q[15]) * inv.z;
+                const float anx = std::fmaf(org[0], inv.x, -oiN.x), any_ = std::fmaf(org[1], inv.y, -oiN.y), anz = std::fmaf(org[2], inv.z, -oiN.z);
+                const float afx = std::fmaf(org[0], inv.x, -oiF.x), afy = std::fmaf(org[1], inv.y, -oiF.y), afz = std::fmaf(org[2], inv.z, -oiF.z);
+                const bool negx = inv.x < 0.0f, negy = inv.y < 0.0f, negz = inv.z < 0.0f;
+                const uint32_t lox = q[8], loy = q[9], loz = q[10], hix = q[11], hiy = q[12], hiz = q[13];
+                const uint32_t nrx = negx ? hix : lox, frx = negx ? lox : hix;
+                const uint32_t nry = negy ? hiy : loy, fry = negy ? loy : hiy;
+                const uint32_t nrz = negz ? hiz : loz, frz = negz ? loz : hiz;
+                uint32_t ref[4] = {q[4], q[5], q[6], q[7]}, key[4];
+                for (int c = 0; c < 4; c++) {
+                    const float tnx = std::fmaf(ub(nrx, c), mx, anx), tfx = std::fmaf(ub(frx, c), mx, afx);
+                    const float tny = std::fmaf(ub(nry, c), my, any_), tfy = std::fmaf(ub(fry, c), my, afy);
+                    const float tnz = std::fmaf(ub(nrz, c), mz, anz), tfz = std::fmaf(ub(frz, c), mz, afz);
+                    const float tn = std::fmax(std::fmax(tnx, tny), std::fmax(tnz, 0.0f));
+                    const float tf = std::fmin(std::fmin(tfx, tfy), std::fmin(tfz, best_t)) * 1.000001f;
+                    const bool hit = tn <= tf && ref[c] != 0xFFFFFFFFu;
+                    key[c] = hit ? asU(tn) : 0xFFFFFFFFu;
+                }
+                auto cswap = [&](int a, int b) {
+                    if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(ref[a], ref[b]); }
+                };
+                cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+                if (key[0] == 0xFFFFFFFFu) {
+                    if (stack.empty()) cur = DONE; else { cur = stack.back(); stack.pop_back(); }
+                } else {
+                    if (key[3] != 0xFFFFFFFFu) stack.push_back(ref[3]);
+                    if (key[2] != 0xFFFFFFFFu) stack.push_back(ref[2]);
+                    if (key[1] != 0xFFFFFFFFu) stack.push_back(ref[1]);
+                    cur = ref[0];
+                }
+            } else if (pend != DONE) {  // triangle step (rtTriStep / rtTriHit)
+                nt++;
+                const uint32_t slot = (pend & MASK) - (uint32_t)n_nodes, g = tri_order[slot];
+                const Tri &T = s.tris[g];
+                bool hit = false;
+                float t = 0.0f;
+                const float ddotN = dot(d, T.n);
+                if (ddotN != 0) {
+                    const float podotN = dot(T.A - o, T.n);
+                    t = podotN / ddotN;
+                    if (!(t < 0) && t <= best_t) {
+                        const V3 td = o + t * d;
+                        const V3 w0 = cross(T.B - td, T.C - td), w1 = cross(T.C - td, T.A - td), w2 = cross(T.A - td, T.B - td);
+                        hit = !(dot(T.n, w0) < 0 || dot(T.n, w1) < 0 || dot(T.n, w2) < 0);
+                    }
+                }
+                const int obj = tri_object[g];
+                const uint32_t rk = rank[g];
+                const bool take = hit && (t < best_t || (t == best_t && best_id != MISS && (obj < best_obj || (obj == best_obj && rk < best_rank))));
+                if (take) { best_t = t; best_id = slot; best_obj = obj; best_rank = rk; }
+                if ((pend >> 28) & 7u) pend += 1u - 0x10000000u; else pend = DONE;
+            }
+            if (cur == DONE && pend == DONE) break;
+        }
+        out_nodes[i] = nn;
+        out_tris[i] = nt;
+        if (out_slot) out_slot[i] = best_id == MISS ? -1 : (int64_t)best_id;
+    }
+    return 0;
+}
+
 int ro_reference_order(const ro_scene *rs, uint32_t *rank) {
     uint32_t next = 0;
     for (const Mesh &m : rs->s.meshes) orderRef(m, 0, next, rank);

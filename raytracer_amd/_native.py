@@ -151,6 +151,7 @@ def hip_lib():
     lib.rt_eval_texture.argtypes = [VP, I32, I64, VP, VP]
     lib.rt_eval_perlin.argtypes = [VP, I64, VP, VP]
     lib.rt_get_bvh.argtypes = [VP, P(I64), VP, P(I64), VP]
+    lib.rt_get_bvh_info.argtypes = [VP, P(C.c_uint32), P(C.c_float), P(I32), P(I32)]
     lib.rt_bvh_check.argtypes = [I64, VP, VP, VP, I32, P(I64), P(C.c_uint64), P(I64)]
     _hip = lib
     return lib

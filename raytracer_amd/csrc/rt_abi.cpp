@@ -619,7 +619,7 @@ int rt_trace_batch(rt_context *ctx, int64_t n, const float *rays, int32_t depth,
     rt_stats local{};
     rt_stats *st = stats ? stats : &local;
     std::memset(st, 0, sizeof *st);
-    int rc = traceBatch(ctx, n, rays, depth, out_color, out_hits, out_shadow, st);
+    int rc = traceBatch(ctx, n, rays, depth, out_color, out_hits, out_shadow, st, stats != nullptr);
     st->primary_samples = (uint64_t)n;
     if (!rc && st->queue_overflow) rc = fail("wavefront queue overflow");
     return rc;
@@ -746,6 +746,14 @@ int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_trian
     return 0;
 }
 
+int rt_get_bvh_info(rt_context *ctx, uint32_t *root_ref, float *bound, int32_t *max_stack, int32_t *lds_stack_entries) {
+    if (!ctx || !ctx->committed) return fail("rt_get_bvh_info: no committed scene");
+    if (root_ref) *root_ref = ctx->bvh.root_ref;
+    if (bound) *bound = ctx->dev.bound;
+    if (max_stack) *max_stack = ctx->bvh.max_stack;
+    if (lds_stack_entries) *lds_stack_entries = ctx->cfg.stack_entries;
+    return 0;
+}
 
 // ---- rt_multi: one frame over N GPUs of this process ------------------------------------------------------------------
 // Stands where `#pragma omp parallel for schedule(dynamic, 1)` over the 16x16 tiles stood (main.cpp:607): the tiles are

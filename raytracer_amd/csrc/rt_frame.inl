@@ -701,8 +701,10 @@ int renderTilesStatic(rt_context *ctx, const rt_camera *cam, const rt_render_par
 }
 
 // ---- rt_trace_batch: trace_ray (main.cpp:221-233) for arbitrary rays -- a batch is a "chunk" of n one-sample pixels ----
+// count: the statistics build of the traversal kernels (records fetched, longest walk -> rt_stats), as rt_render's collect_stats & 1
 int traceBatch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, float *out_color, rt_hit *out_hits, uint8_t *out_shadow,
-               rt_stats *st) {
+               rt_stats *st, bool count) {
+    const int sl = count ? 1 : 0;
     const int nl = std::max<int>(1, (int)ctx->lights.size());
     RtLaunchCfg cfg = ctx->cfg;
     cfg.stream = ctx->stream;
@@ -751,16 +753,16 @@ int traceBatch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, flo
             rtLaunchIterCtl(cfg, q, par ^ 1, 0u, j == 0, q.prim_n);
             if (j == 0) {
                 rtLaunchRaysFromHost(cfg, d_rays.p, m, q);
-                if (cfg.packets) rtLaunchPacket(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0);
-                else rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0u, 0);
+                if (cfg.packets) rtLaunchPacket(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, sl);
+                else rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, 0, 0u, sl);
                 // the closest hits of the batch are reported from this pass
                 if (out_hits || out_shadow) rtLaunchHitInfo(cfg, ctx->dev, ctx->bvh.root_ref, q, m, out_hits ? d_hits.p : nullptr, out_shadow ? d_sh.p : nullptr);
             } else {
-                rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0u, 0);
+                rtLaunchClosest(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0u, sl);
             }
             rtLaunchShade(cfg, ctx->dev, q, par, depth, 1, 0, nullptr, false, (uint64_t)m << j);
-            rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0);
-            rtLaunchSplitRounds(cfg, ctx->dev, ctx->bvh.root_ref, q, par, 0);
+            rtLaunchAny(cfg, ctx->dev, ctx->bvh.root_ref, q, par, sl);
+            rtLaunchSplitRounds(cfg, ctx->dev, ctx->bvh.root_ref, q, par, sl);
             st->launches_closest++;
             st->launches_any++;
         }

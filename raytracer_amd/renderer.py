@@ -142,6 +142,12 @@ class Renderer:
         self._check(self.lib.rt_get_bvh(self._ctx, C.byref(nn), _p(nodes), C.byref(nt), _p(order)))
         return nodes, order
 
+    def get_bvh_info(self):
+        """root reference, error-bound scale, deepest stack and LDS stack entries of the committed tree (rt_get_bvh_info)"""
+        root, bound, ms, le = C.c_uint32(), C.c_float(), C.c_int32(), C.c_int32()
+        self._check(self.lib.rt_get_bvh_info(self._ctx, C.byref(root), C.byref(bound), C.byref(ms), C.byref(le)))
+        return dict(root_ref=root.value, bound=bound.value, max_stack=ms.value, lds_stack_entries=le.value)
+
 
 def hits_to_arrays(hits):
     """(N.Hit * n) -> dict of numpy arrays (field names of include/rt_hip.h: rt_hit)"""

@@ -8,7 +8,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "stress-diagonal:733"
 W, H, SPP = (int(x) for x in (sys.argv[2:5] if len(sys.argv) > 4 else (3840, 2160, 16)))
 counted = len(sys.argv) > 5 and sys.argv[5] == "count"
 r = Renderer(0).set_scene(FlatScene.builtin(name))
-r.render(W, H, spp=SPP, want=())                                   # sizes the queues from the scene's fan-out
+r.render(max(W // 8, 64), max(H // 8, 64), spp=SPP, want=())      # a SMALL frame sizes the queues from the scene's fan-out (1.6 % of the
+                                                                   # measured frame's samples: the rocprofv3 passes sum over the process)
 st = r.render(W, H, spp=SPP, collect_stats=2, want=())["stats"]    # the frame the counters are read on
 out = {"scene": name, "width": W, "height": H, "spp": SPP, "ms_total": st["ms_total"], "ms_trace": st["ms_trace"], "ms_shade": st["ms_shade"],
        "chunks": st["chunks"], "rays_closest": st["rays_closest"], "rays_shadow": st["rays_shadow"], "triangles": st["n_triangles"],

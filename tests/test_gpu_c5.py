@@ -13,11 +13,21 @@ from conftest import get_scene, image_metrics
 pytestmark = pytest.mark.gpu
 
 
-def test_c5_733_replicas_commit_and_render():
+_c5 = {}
+
+
+def c5_renderer():
+    """the 50 M-triangle scene committed once for the tests of this module (the commit takes ~12 s)"""
     from raytracer_amd.renderer import Renderer
+    if "r" not in _c5:
+        _c5["r"] = Renderer(0).set_scene(get_scene("stress:733", False))
+    return _c5["r"]
+
+
+def test_c5_733_replicas_commit_and_render():
     scene = get_scene("stress:733", False)
     assert scene.n_triangles == 733 * 68202 == 49992066
-    r = Renderer(0).set_scene(scene)
+    r = c5_renderer()
     cs = r.commit_stats()
     print(f"stress:733 commit: BVH build {cs['ms_bvh_build'] / 1e3:.1f} s, reference order {cs['ms_reference_order'] / 1e3:.2f} s, "
           f"records {cs['ms_records'] / 1e3:.1f} s, upload {cs['ms_upload'] / 1e3:.2f} s; {cs['bvh_nodes']} nodes")
@@ -45,7 +55,35 @@ def test_c5_733_replicas_commit_and_render():
     assert sa["max_walk_any"] < 20000
     hit = (a["primid"] != 0xFFFFFFFF).mean()
     assert hit > 0.5
-    r.close()
+
+
+def test_c5_full_frame_7680x4320_256spp_is_deterministic_and_chunk_independent():
+    """BASELINE.json configs[4] at its STATED frame size: 7680x4320 @256 spp = 8.49 G primary samples over 50 M triangles (no
+    oracle can render that: the checks are the size-independent ones -- bit-identical images across runs and chunkings,
+    ray bookkeeping, no overflow; parity of this scene's kernels against the oracle is the stress:64 test below)."""
+    import torch
+    r = c5_renderer()
+    W, H, spp = 7680, 4320, 256
+    n = r.tile_counts(W, H, 0, 1)[0]
+    assert n == (W // 16) * (H // 16)
+    out = []
+    for kw in ({}, {"chunk_samples": 12 << 20}):
+        t8 = torch.zeros(n, 256, 3, dtype=torch.uint8, device="cuda:0")
+        tp = torch.zeros(n, 256, dtype=torch.int32, device="cuda:0")
+        st = r.render_tiles_device(W, H, 0, 1, t8.data_ptr(), 0, tp.data_ptr(), spp=spp, **kw)
+        torch.cuda.synchronize()
+        out.append((t8, tp, st))
+        print(f"stress:733 {W}x{H}@{spp} {kw or 'library chunking'}: {st['ms_total'] / 1e3:.2f} s in {st['chunks']} chunks, "
+              f"{(st['rays_closest'] + st['rays_shadow']) / st['ms_total'] / 1e3:.0f} Mrays/s traced")
+    (a8, ap, sa), (b8, bp, sb) = out
+    assert torch.equal(a8, b8) and torch.equal(ap, bp)
+    assert sa["primary_samples"] == sb["primary_samples"] == W * H * spp
+    for k in ("rays_closest", "rays_shadow", "shadow_culled", "shadow_zero", "hits_shaded"):
+        assert sa[k] == sb[k], k
+    assert sa["queue_overflow"] == sb["queue_overflow"] == 0 and sa["chunks"] != sb["chunks"]
+    assert sa["hits_shaded"] <= sa["rays_closest"] and sa["rays_closest"] >= sa["primary_samples"]
+    assert float((ap != -1).float().mean()) > 0.5
+    _c5.pop("r").close()
 
 
 def test_c5_lite_sampled_tiles_against_the_oracle_without_packets(monkeypatch, oracle_for):

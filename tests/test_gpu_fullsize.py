@@ -82,3 +82,32 @@ def test_full_frame_64spp_is_deterministic_chunk_and_partition_independent():
         del r8, rp
     for k in tot:
         assert tot[k] == sa[k], k
+
+
+def test_bunny_full_frame_4k_64spp_is_deterministic_across_accumulation_paths():
+    """BASELINE.json configs[2] (C3: the bunny scene) at its STATED size, 3840x2160 @64 spp.  The first frame after rt_commit adds
+    its level-0 shadow results with atomics; the scene's shadow rays are mostly level-0 rays, so the following frames STORE them
+    and fold them afterwards (RtQueues::occ0, k_fold0): the same fixed-point integers, hence the same image bit for bit -- also
+    for another chunking.  Plus the ray bookkeeping of the whole frame."""
+    import torch
+    from raytracer_amd.renderer import Renderer
+    r = Renderer(0).set_scene(get_scene("bunny", False))
+    n = r.tile_counts(W, H, 0, 1)[0]
+    frames = []
+    for kw in ({}, {}, {"chunk_samples": 24 << 20}):
+        t8 = torch.zeros(n, 256, 3, dtype=torch.uint8, device="cuda:0")
+        tp = torch.zeros(n, 256, dtype=torch.int32, device="cuda:0")
+        tf = torch.zeros(n, 256, 3, dtype=torch.float32, device="cuda:0")
+        st = r.render_tiles_device(W, H, 0, 1, t8.data_ptr(), tf.data_ptr(), tp.data_ptr(), spp=64, **kw)
+        torch.cuda.synchronize()
+        frames.append((t8, tp, tf.view(torch.int32), st))
+        print(f"bunny {W}x{H}@64 {kw or 'library chunking'}: {st['ms_total']:.1f} ms, {st['chunks']} chunks, {st['rays_closest']} + {st['rays_shadow']} rays")
+    a = frames[0]
+    for b in frames[1:]:
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for k in ("primary_samples", "rays_closest", "rays_shadow", "shadow_culled", "shadow_zero", "hits_shaded"):
+            assert a[3][k] == b[3][k], k
+        assert b[3]["queue_overflow"] == 0
+    sa = a[3]
+    assert sa["primary_samples"] == W * H * 64 and sa["rays_closest"] >= sa["primary_samples"] and sa["hits_shaded"] <= sa["rays_closest"]
+    r.close()
