@@ -489,10 +489,13 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
     if (const char *e = getenv("RT_WORKSPACE_FRACTION")) ws_frac = std::min(0.875, std::max(0.01, atof(e)));
     bool fuse = true;  // RT_FUSE=0: the traversal phases of an iteration as launches of their own (ms_any / ms_closest / ms_packet)
     if (const char *e = getenv("RT_FUSE")) fuse = atoi(e) != 0;
-    // RT_LANES=2: two pipelines side by side.  Measured on the 4K frame: the second lane's launches do fill the ends of the
-    // first one's (one lane with chunks of the same size is 10 % slower), but two lanes halve the chunk a workspace can
-    // hold, which costs what the overlap gains: 463 vs 443-453 ms.  One lane unless asked.
-    in.lanes = 1;
+    // RT_LANES=2: two pipelines side by side.  Measured on the 4K competition frame: the second lane's launches do fill the
+    // ends of the first one's (one lane with chunks of the same size is 10 % slower), but two lanes halve the chunk a workspace
+    // can hold, which costs what the overlap gains: 446 vs 435 ms in 30 GB, 463 vs 452 in 16 GB, 500 vs 500 in 8 GB.
+    // Two lanes where the tree is large (>= 8 Mi triangles): its walks leave L2 and run to hundreds of steps, a launch's tail
+    // is then milliseconds of a mostly idle chip, and the other lane's launches are what fills it -- the 50 M-triangle frame
+    // at 64 spp: 1089 -> 1019 ms in the same 30 GB (profiles/r03_lanes.md).
+    in.lanes = ctx->info.n_triangles >= ((uint64_t)8 << 20) ? 2 : 1;
     if (const char *e = getenv("RT_LANES")) in.lanes = std::max(1, std::min(2, atoi(e)));
     std::vector<uint32_t> hc(2 * RT_CNT_WORDS, 0);
     bool started = false;  // ev.a is recorded once the workspace exists: ms_total is GPU time, not hipMalloc time

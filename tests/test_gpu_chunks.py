@@ -79,3 +79,29 @@ def test_level0_shadow_results_stored_or_added_same_bits(name):
     assert np.array_equal(out["0"]["rgbf"].view(np.uint32), out["1"]["rgbf"].view(np.uint32))
     for k in ("rays_closest", "rays_shadow", "shadow_zero", "shadow_unoccluded", "hits_shaded"):
         assert out["0"]["stats"][k] == out["1"]["stats"][k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["competition", "bunny"])
+def test_two_lanes_same_bits(name):
+    """Two pipelines side by side (what scenes of >= 8 Mi triangles get by default; RT_LANES forces it): chunk c runs in lane
+    c % 2, each lane with queues, counters and a stream of its own -- the image and the ray counts are those of one lane."""
+    from raytracer_amd.renderer import Renderer
+    r = Renderer(0).set_scene(get_scene(name, False))
+    w, h, spp = 1280, 720, 16
+    out = {}
+    for lanes in ("1", "2"):
+        os.environ["RT_LANES"] = lanes
+        try:
+            r.render(w, h, spp=spp, chunk_samples=1 << 20, want=())
+            out[lanes] = r.render(w, h, spp=spp, chunk_samples=1 << 20, collect_stats=1, want=("rgb8", "rgbf", "primid"))
+        finally:
+            del os.environ["RT_LANES"]
+    assert out["2"]["stats"]["chunks"] >= 8
+    for k in ("rgb8", "primid"):
+        assert np.array_equal(out["1"][k], out["2"][k]), k
+    assert np.array_equal(out["1"]["rgbf"].view(np.uint32), out["2"]["rgbf"].view(np.uint32))
+    for k in ("rays_closest", "rays_shadow", "shadow_zero", "shadow_unoccluded", "hits_shaded", "nodes_visited", "tris_tested"):
+        if k in ("nodes_visited", "tris_tested"):
+            continue  # (how many nodes a ray visits depends on its wave's phase votes)
+        assert out["1"]["stats"][k] == out["2"]["stats"][k], k
