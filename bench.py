@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-roofline", action="store_true", help="skip the two instrumented passes")
     ap.add_argument("--cpu-sample", default="480x360")
+    ap.add_argument("--sizing-frame", action="store_true",
+                    help="render one frame at 1/8 of the width and height first (untimed): the library then knows the scene's fan-out "
+                         "and plans the full frames like any later frame.  For profiler passes that sum over the process "
+                         "(--steps 1 --warmup 0 --sizing-frame: 1.6 %% of the samples ride along instead of a worst-case first frame)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the gather even with one rank (rehearses the RCCL path on a 1-GPU box)")
     ap.add_argument("--multi-abi", action="store_true",
@@ -172,6 +176,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.sizing_frame:
+        # (with the counting build of the kernels: their launches carry other names in a profiler's kernel table, which then
+        # holds full-size launches only under the plain names)
+        r.render(max(W // 8, 16), max(H // 8, 16), spp=a.spp, max_depth=a.depth, collect_stats=1, want=())
     for _ in range(a.warmup):
         frame()
     sync()
@@ -230,8 +238,14 @@ def main():
     if not a.no_roofline:
         # EVERY rank renders the two instrumented frames: a frame ends in a collective (the gather), so rank 0 alone
         # would wait for peers that have moved on.  The figures reported are rank 0's (its share of the tiles).
+        lanes_env = os.environ.get("RT_LANES")
+        os.environ["RT_LANES"] = "1"   # one pipeline: the kernels run one after the other, a launch's duration is its own
         timed = frame(collect=2)       # per-kernel-class HIP-event timing on the launch stream
         counted = frame(collect=1)     # in-kernel record counters (stats build of the same kernels, counts only)
+        if lanes_env is None:
+            del os.environ["RT_LANES"]
+        else:
+            os.environ["RT_LANES"] = lanes_env
     if rank == 0 and not a.no_roofline:
         from raytracer_amd._native import kernel_source_hash
         pc, pa = counted["prof_packet_closest"], counted["prof_packet_any"]
@@ -271,6 +285,7 @@ def main():
                 # per launch of THIS run (the profiled frame may have been cut into more chunks, i.e. more launches)
                 traffic = t["kernels"][name]["hbm_bytes_per_frame"] / launches
                 traffic_src = "profiles/r03_pmc_traffic.json (same kernel sources, hash %s)" % khash
+        rec_bytes = 64.0 * (nodes + tris)   # what the walks ask the memory system for: one 64-byte record per node step / triangle test
         result["roofline"] = {
             "kernel": name, "bound": "valu_fp32", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / VALU_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -281,6 +296,31 @@ def main():
                     "note": "queue records + accumulator updates only; BVH / triangle records are L2 / Infinity Cache resident"},
             "note": "no dense contraction on this path (SURVEY.md 8d): the ceiling is the FP32 vector unit; flops = 80 per 4-wide "
                     "node step + 80 per triangle test, both counted in-kernel in this run"}
+        if a.scene.startswith("stress"):
+            # the 50 M-triangle tree (3.9 GB of records) is the configuration whose record fetches leave the
+            # caches.  Bound = HBM: `achieved` = record bytes the walks fetch (64 B each, counted in-kernel in this run) per
+            # second of kernel time; `traffic` = what the L2 really fetched from the memory side for this kernel, from the
+            # committed rocprofv3 FETCH_SIZE pass of this scene and camera (profiles/r03_c5_pmc.json), per launch.
+            fl = result["roofline"]
+            gbs = rec_bytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+            fl["valu_fp32"] = {"achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS}
+            fl.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                       "record_bytes_per_launch": rec_bytes / launches,
+                       "note": "achieved = 64-byte records fetched by the walks (node steps + triangle tests, counted in-kernel in this run) / kernel "
+                               "time: an upper bound on what reaches HBM (L1 / L2 / Infinity Cache hits included); `traffic` and `l2` say "
+                               "how much of it did"})
+            ppath = os.path.join(REPO, "profiles", "r03_c5_pmc.json")
+            if os.path.exists(ppath):
+                pj = json.load(open(ppath))
+                cam = pj.get("cameras", {}).get(a.scene.split(":")[0])
+                if cam:
+                    per_ray = cam["k_trace_hbm_read_bytes_x2"] / max(cam["rays"], 1)   # the profiled frame may differ in size: per ray
+                    fl["traffic"] = per_ray * nrays / launches
+                    fl["traffic_source"] = ("profiles/r03_c5_pmc.json (%s; HBM read bytes per traced ray x this run's rays; kernel sources %s)"
+                                            % (cam["workload"], "match" if pj.get("kernel_source_hash") == khash else "DIFFER from this build"))
+                    fl["hbm_measured"] = {"read_GBs": cam["hbm_read_GBs_x2"], "frac_of_peak": cam["hbm_frac_of_peak_x2"],
+                                          "read_GBs_raw_counter": cam["hbm_read_GBs_raw"]}
+                    fl["l2"] = {"hit_rate": cam["l2_hit_rate"], "l1_hit_rate": cam["l1_hit_rate"], "source": "profiles/r03_c5_pmc.json"}
         pr = counted["prof_any" if name == "k_any" else "prof_closest"]  # counted in-kernel (cheap statistics build; k_trace: its closest-hit phase)
         if pr[2] and pr[5] and pr[8]:
             result["roofline"]["lanes"] = {

@@ -4,7 +4,7 @@
 tag=${1:-pmc_valu}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
-BENCH="python3 bench.py --steps 1 --warmup 0 --no-cpu --no-roofline"
+BENCH="python3 bench.py --sizing-frame --steps 1 --warmup 0 --no-cpu --no-roofline"
 timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --stats -d gpurun_out/$tag/trace -- $BENCH > gpurun_out/$tag/trace.log 2>&1 || { tail -5 gpurun_out/$tag/trace.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/$tag/sq -- $BENCH > gpurun_out/$tag/sq.log 2>&1 || { tail -5 gpurun_out/$tag/sq.log; exit 1; }
 timeout -s KILL 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/$tag/sq2 -- $BENCH > gpurun_out/$tag/sq2.log 2>&1 || { tail -5 gpurun_out/$tag/sq2.log; exit 1; }
