@@ -255,7 +255,8 @@ def main():
             "k_any": (timed["ms_any"], timed["launches_any"], counted["nodes_visited_any"], counted["tris_tested_any"], counted["rays_shadow"]),
             # the fused traversal launch (one per iteration): shadow rays + bounce rays per lane, primary rays as packets
             # (a packet step is counted once per lane that takes part in it: prof_packet[2] / [4])
-            "k_trace": (timed["ms_trace"], max(timed["launches_closest"], timed["launches_any"]),
+            # (T iterations walk T ray queues and T shadow queues in T + 1 launches: the first has no shadow rays yet, the last no bounce rays any more)
+            "k_trace": (timed["ms_trace"], max(timed["launches_closest"], timed["launches_any"]) + 1,
                         counted["nodes_visited"] + counted["nodes_visited_any"] + pc[2],
                         counted["tris_tested"] + counted["tris_tested_any"] + pc[4], counted["rays_closest"] + counted["rays_shadow"]),
         }
