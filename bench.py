@@ -332,13 +332,13 @@ def main():
         if os.path.exists(cpath):  # committed L1 / L2 hit-rate passes of this workload: only with matching kernel sources
             cj = json.load(open(cpath))
             c = cj.get("kernels", {}).get(name)
-            if cj.get("kernel_source_hash") == khash and c:
+            if cj.get("kernel_source_hash") == khash and c and cj.get("workload") == result["config"]["workload"]:
                 result["roofline"]["l2"] = dict(c, source="profiles/r03_pmc_cache.json (same kernel sources)")
         vpath = os.path.join(REPO, "profiles", "r03_pmc_valu.json")
         if os.path.exists(vpath):  # committed rocprofv3 --pmc SQ pass of this workload: only with matching kernel sources
             vj = json.load(open(vpath))
             v = vj.get("kernels", {}).get(name)
-            if vj.get("kernel_source_hash") == khash and v and v.get("SQ_INSTS_VALU"):
+            if vj.get("kernel_source_hash") == khash and v and v.get("SQ_INSTS_VALU") and vj.get("workload", "").startswith(result["config"]["workload"]):
                 result["roofline"]["issue"] = {
                     "valu_wave_insts_per_ray": v["SQ_INSTS_VALU"] / max(nrays, 1),
                     "valu_issue_frac_of_2cyc_peak": v.get("valu_issue_frac"), "sclk_ghz_profiled": v.get("sclk_ghz"),

@@ -1,6 +1,7 @@
 """One frame of a built-in scene (default: the 50 M-triangle stress scene, second camera) -- the program the rocprofv3 passes of
 scripts/gpu_r3_c5.sh run.  Prints one JSON line: frame time, rays, records fetched (in-kernel counters of a separate frame)."""
 import json, os, sys
+os.environ.setdefault("RT_LANES", "1")  # one pipeline: the kernels run one after the other, a launch's time is its own (the default for this scene is two)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracer_amd import FlatScene
 from raytracer_amd.renderer import Renderer
