@@ -267,8 +267,15 @@ void refOrder(const float *v0, const float *v1, const float *v2, std::vector<uin
 
 
 // ---- collapse to 4 children per node + quantisation -------------------------------------------------------------
+// Level by level: the 4-wide nodes of one level are independent of each other, so every level is two parallel passes over
+// its nodes -- (1) choose the up to four children of each (open the inner child with the largest surface until there are
+// four), count the inner ones, prefix-sum the counts: that IS the breadth-first numbering (the next level's nodes in parent
+// order, children in slot order: the top levels, which every ray visits, become a prefix of the array and siblings stay
+// close); (2) quantise the child boxes and write both node forms.  The tree does not depend on the thread count.
+// (Round 2 emitted the nodes depth first on one thread and renumbered afterwards: 2.8 s of the 50 M-triangle commit.)
 struct Collapser {
     const std::vector<RtNode> &bn;
+    int threads = 1;
     std::vector<RtNode4> out;
     std::vector<RtNodeP> outP;  // same indices as `out`
     int maxDepth = 0, maxStack = 0;
@@ -280,26 +287,26 @@ struct Collapser {
     }
     static uint32_t leafRef(const RtNode &n) { return 0x80000000u | ((n.b - 1u) << 28) | n.a; }  // slot; rebased later
 
-    // emits the 4-wide node of binary inner node `b`; `pending` = stack entries that can be live above it
-    uint32_t emit(uint32_t b, int depth, int pending) {
-        const uint32_t self = (uint32_t)out.size();
-        out.emplace_back();
-        outP.emplace_back();
-        uint32_t kids[4] = {bn[b].a, bn[b].a + 1, 0, 0};
+    struct Item { uint32_t b; int pending; };  // binary inner node to emit; stack entries that can be live above it
+    struct Kids { uint32_t k[4]; int nk, inner; };
+
+    Kids choose(uint32_t b) const {
+        Kids r;
+        r.k[0] = bn[b].a; r.k[1] = bn[b].a + 1; r.k[2] = r.k[3] = 0;
         int nk = 2;
         while (nk < 4) {  // open the inner child with the largest surface
             int pick = -1;
             float best = -1.0f;
             for (int k = 0; k < nk; k++)
-                if (bn[kids[k]].b == 0 && halfArea(bn[kids[k]]) > best) {
-                    best = halfArea(bn[kids[k]]);
+                if (bn[r.k[k]].b == 0 && halfArea(bn[r.k[k]]) > best) {
+                    best = halfArea(bn[r.k[k]]);
                     pick = k;
                 }
             if (pick < 0) break;
-            const uint32_t open = kids[pick];
-            for (int k = nk; k > pick + 1; k--) kids[k] = kids[k - 1];
-            kids[pick] = bn[open].a;
-            kids[pick + 1] = bn[open].a + 1;
+            const uint32_t open = r.k[pick];
+            for (int k = nk; k > pick + 1; k--) r.k[k] = r.k[k - 1];
+            r.k[pick] = bn[open].a;
+            r.k[pick + 1] = bn[open].a + 1;
             nk++;
         }
         // Child slots in order of surface, smallest first.  Closest-hit walks sort the hit children by distance, so the
@@ -307,9 +314,17 @@ struct Collapser {
         // and the small boxes are where the geometry is dense: an occluded shadow ray finds its occluder sooner
         // (k_any 132 -> 128 ms on the 4K competition frame; largest first: 138).
         for (int i = 1; i < nk; i++)
-            for (int j = i; j > 0 && halfArea(bn[kids[j]]) < halfArea(bn[kids[j - 1]]); j--) std::swap(kids[j], kids[j - 1]);
-        maxDepth = std::max(maxDepth, depth);
-        maxStack = std::max(maxStack, pending + nk - 1);
+            for (int j = i; j > 0 && halfArea(bn[r.k[j]]) < halfArea(bn[r.k[j - 1]]); j--) std::swap(r.k[j], r.k[j - 1]);
+        r.nk = nk;
+        r.inner = 0;
+        for (int k = 0; k < nk; k++) r.inner += bn[r.k[k]].b == 0 ? 1 : 0;
+        return r;
+    }
+
+    // writes node `self`; its inner children get the indices first_child, first_child + 1, ... in slot order
+    void fill(uint32_t self, const Kids &kd, uint32_t first_child, float &bnd) {
+        const int nk = kd.nk;
+        const uint32_t *kids = kd.k;
         // frame = union of the children's (padded) boxes
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < nk; k++)
@@ -319,7 +334,7 @@ struct Collapser {
             }
         double scale[3];
         for (int a = 0; a < 3; a++) {
-            bound = std::fmax(bound, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
+            bnd = std::fmax(bnd, std::fmax(std::fabs(lo[a]), std::fabs(hi[a])));
             const double ext = (double)hi[a] - (double)lo[a];
             int e = -100;
             if (ext > 0) e = std::max(-100, (int)std::ceil(std::log2(ext / 255.0)));
@@ -339,9 +354,10 @@ struct Collapser {
                 qhi[a] |= (uint32_t)h << (8 * k);
             }
         }
+        uint32_t next = first_child;
         for (int k = 0; k < nk; k++) {
             const RtNode &c = bn[kids[k]];
-            child[k] = c.b ? leafRef(c) : emit(kids[k], depth + 1, pending + nk - 1);
+            child[k] = c.b ? leafRef(c) : next++;
         }
         RtNode4 &n = out[self];
         n.origin[0] = lo[0]; n.origin[1] = lo[1]; n.origin[2] = lo[2];
@@ -358,7 +374,57 @@ struct Collapser {
         }
         n.qlo[0] = qlo[0]; n.qlo[1] = qlo[1]; n.qlo[2] = qlo[2];
         n.qhi_x = qhi[0]; n.qhi_y = qhi[1]; n.qhi_z = qhi[2];
-        return self;
+    }
+
+    void run(uint32_t root) {
+        out.reserve(bn.size() / 2 + 1);   // (every 4-wide node stands for at least one binary inner node)
+        outP.reserve(bn.size() / 2 + 1);
+        std::vector<Item> level{Item{root, 0}}, nextLevel;
+        std::vector<Kids> kids;
+        std::vector<uint32_t> firstChild;
+        size_t base = 0;
+        for (int depth = 1; !level.empty(); depth++) {
+            const size_t n = level.size();
+            maxDepth = depth;
+            out.resize(base + n);
+            outP.resize(base + n);
+            kids.resize(n);
+            firstChild.resize(n + 1);
+            parallelRange(0, n, threads, [&](int, size_t a, size_t e) {
+                for (size_t i = a; i < e; i++) kids[i] = choose(level[i].b);
+            });
+            uint32_t total = 0;
+            for (size_t i = 0; i < n; i++) {  // (a serial scan: 12 M additions for the 50 M-triangle tree, all levels together)
+                firstChild[i] = total;
+                total += (uint32_t)kids[i].inner;
+            }
+            firstChild[n] = total;
+            nextLevel.resize(total);
+            const int nt = std::max(threads, 1);
+            std::vector<float> tb((size_t)nt, 0.0f);
+            std::vector<int> ts((size_t)nt, 0);
+            parallelRange(0, n, threads, [&](int tid, size_t a, size_t e) {
+                float bnd = 0.0f;
+                int stk = 0;
+                for (size_t i = a; i < e; i++) {
+                    const Kids &kd = kids[i];
+                    const int pend = level[i].pending + kd.nk - 1;
+                    stk = std::max(stk, pend);
+                    fill((uint32_t)(base + i), kd, (uint32_t)(base + n + firstChild[i]), bnd);
+                    uint32_t at = firstChild[i];
+                    for (int k = 0; k < kd.nk; k++)
+                        if (bn[kd.k[k]].b == 0) nextLevel[at++] = Item{kd.k[k], pend};
+                }
+                tb[(size_t)tid] = bnd;
+                ts[(size_t)tid] = stk;
+            });
+            for (int t = 0; t < nt; t++) {
+                bound = std::fmax(bound, tb[(size_t)t]);
+                maxStack = std::max(maxStack, ts[(size_t)t]);
+            }
+            base += n;
+            level.swap(nextLevel);
+        }
     }
 };
 
@@ -439,34 +505,8 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
         for (int a = 0; a < 3; a++) out.bound = std::fmax(out.bound, std::fmax(std::fabs(root.mn[a]), std::fabs(root.mx[a])));
     } else {
         Collapser c{b.nodes};
-        c.out.reserve(b.nodes.size() / 2 + 1);
-        c.emit(1, 1, 0);
-        // renumber breadth first: the top levels, which every ray visits, become a prefix of the array (the traversal
-        // kernels stage that prefix in LDS) and siblings stay close
-        {
-            std::vector<uint32_t> bfs, newIndex(c.out.size());
-            bfs.reserve(c.out.size());
-            bfs.push_back(0);
-            for (size_t h = 0; h < bfs.size(); h++)
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t ch = c.out[bfs[h]].child[k];
-                    if (ch != 0xFFFFFFFFu && !(ch & 0x80000000u)) bfs.push_back(ch);
-                }
-            for (size_t i = 0; i < bfs.size(); i++) newIndex[bfs[i]] = (uint32_t)i;
-            std::vector<RtNode4> re(c.out.size());
-            std::vector<RtNodeP> reP(c.out.size());
-            for (size_t i = 0; i < bfs.size(); i++) {
-                re[i] = c.out[bfs[i]];
-                reP[i] = c.outP[bfs[i]];
-                for (int k = 0; k < 4; k++) {
-                    uint32_t &ch = re[i].child[k];
-                    if (ch != 0xFFFFFFFFu && !(ch & 0x80000000u)) ch = newIndex[ch];
-                    reP[i].child[k] = ch;
-                }
-            }
-            c.out.swap(re);
-            c.outP.swap(reP);
-        }
+        c.threads = threads;
+        c.run(1);
         out.nodes = std::move(c.out);
         out.nodes_p = std::move(c.outP);
         out.root_ref = 0;
@@ -486,6 +526,11 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     if (verbose)
         std::fprintf(stderr, "[rt_bvh] %lld triangles, %d threads: top %.2f s, subtrees %.2f s (%zu tasks), collapse+quantise+renumber %.2f s\n",
                      (long long)n, threads, t1 - t0, t2 - t1, b.tasks.size(), nowSeconds() - t2);
+}
+
+int rtBuildThreads() { return buildThreads(); }
+void rtParallelFor(size_t n, void (*fn)(size_t, size_t, void *), void *arg) {
+    parallelRange(0, n, buildThreads(), [&](int, size_t a, size_t e) { fn(a, e, arg); });
 }
 
 void rtReferenceOrder(int64_t n, const float *v0, const float *v1, const float *v2, const int32_t *object_id,

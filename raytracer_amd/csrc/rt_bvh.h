@@ -19,3 +19,8 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
 
 // rank[t] = position of triangle t in the candidate order of the reference's per-mesh trees
 void rtReferenceOrder(int64_t n, const float *v0, const float *v1, const float *v2, const int32_t *object_id, uint32_t *rank);
+
+// host threads of the build (RT_BUILD_THREADS, else OMP_NUM_THREADS, else the hardware's, at most 16), and
+// fn(begin, end) over [0, n) cut into one contiguous piece per thread (rt_commit's record assembly uses both)
+int rtBuildThreads();
+void rtParallelFor(size_t n, void (*fn)(size_t, size_t, void *), void *arg);
