@@ -307,8 +307,9 @@ int rt_eval_texture(rt_context *ctx, int32_t texture_id, int64_t n, const float 
 int rt_eval_perlin(rt_context *ctx, int64_t n, const float *p, float *out);
 
 /* Read back the committed BVH (for the oracle-side counter checks): nodes[n_nodes*16] 32-bit words as stored
- * (64-byte 4-wide quantised nodes, layout in DESIGN.md), tri_order[n_triangles] = global triangle index held by
- * BVH slot i.  Pass NULL to query sizes only. */
+ * (64-byte 4-wide quantised nodes, layout in DESIGN.md), tri_order[*n_triangles] = global triangle index held by
+ * BVH slot i.  *n_triangles is the number of SLOTS, >= the number of triangles: large triangles are cut into pieces
+ * before the build and own one slot (one copy of their record) per piece.  Pass NULL to query sizes only. */
 int rt_get_bvh(rt_context *ctx, int64_t *n_nodes, float *nodes, int64_t *n_triangles, uint32_t *tri_order);
 /* ... and what a walk over it needs besides: the root's reference (node 0, or a leaf reference for a tree of <= 4 triangles),
  * the slab test's error-bound scale (max |coordinate| of any node box), the deepest traversal stack and how many of its

@@ -53,7 +53,7 @@ def lib():
         L.ro_eval_texture.argtypes = [VP, C.c_int32, C.c_int64, VP, VP]
         L.ro_eval_perlin.argtypes = [C.c_int64, VP, VP]
         L.ro_reference_order.argtypes = [VP, VP]
-        L.ro_walk_counts.argtypes = [VP, C.c_uint32, C.c_float, C.c_int64, VP, VP, VP, VP, C.c_int64, VP, VP, VP, VP]
+        L.ro_walk_counts.argtypes = [VP, C.c_uint32, C.c_float, C.c_int64, VP, VP, VP, VP, C.c_int64, VP, VP, VP, VP, VP]
         _lib = L
     return _lib
 
@@ -140,7 +140,7 @@ class Oracle:
         lib().ro_eval_texture(self._h, tex_id, len(uv), _p(uv), _p(out))
         return out
 
-    def walk_counts(self, nodes, tri_order, info, rays):
+    def walk_counts(self, nodes, tri_order, info, rays, slot_tests=None):
         """node steps / triangle tests / closest BVH slot per ray of the KERNEL's closest-hit walk over the committed tree
         (nodes, tri_order: Renderer.get_bvh(); info: Renderer.get_bvh_info()), restated on the CPU (ro_walk_counts)"""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
@@ -151,7 +151,7 @@ class Oracle:
         n = len(rays)
         on, ot, sl = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.int64)
         lib().ro_walk_counts(self._h, info["root_ref"], info["bound"], len(nodes), _p(nodes), _p(tri_order), _p(tri_object), _p(rank),
-                             n, _p(rays), _p(on), _p(ot), _p(sl))
+                             n, _p(rays), _p(on), _p(ot), _p(sl), _p(slot_tests))
         return on, ot, sl
 
     def reference_order(self):

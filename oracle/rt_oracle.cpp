@@ -955,7 +955,7 @@ static void orderRef(const Mesh &m, int node, uint32_t &next, uint32_t *rank) {
 // primitives (the test scene has none).  out_slot = BVH slot of the closest triangle or -1.
 int ro_walk_counts(const ro_scene *rs, uint32_t root_ref, float bound, int64_t n_nodes, const uint32_t *nodes, const uint32_t *tri_order,
                    const int32_t *tri_object, const uint32_t *rank, int64_t n_rays, const float *rays, uint64_t *out_nodes,
-                   uint64_t *out_tris, int64_t *out_slot) {
+                   uint64_t *out_tris, int64_t *out_slot, uint32_t *slot_tests /* per BVH slot: tests over all rays, or NULL */) {
     const Scene &s = rs->s;
     const uint32_t LEAF = 0x80000000u, DONE = 0xFFFFFFFFu, MASK = 0x0FFFFFFFu, MISS = 0xFFFFFFFFu;
     auto safeInv = [](float d) {
@@ -1024,6 +1024,10 @@ int ro_walk_counts(const ro_scene *rs, uint32_t root_ref, float bound, int64_t n
             } else if (pend != DONE) {  // triangle step (rtTriStep / rtTriHit)
                 nt++;
                 const uint32_t slot = (pend & MASK) - (uint32_t)n_nodes, g = tri_order[slot];
+                if (slot_tests) {
+#pragma omp atomic
+                    slot_tests[slot]++;
+                }
                 const Tri &T = s.tris[g];
                 bool hit = false;
                 float t = 0.0f;

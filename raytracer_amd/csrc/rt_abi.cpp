@@ -422,11 +422,13 @@ int commitHost(rt_context *ctx, CommitImage &img) {
     // record array: nodes first, then one 64-byte record per triangle in leaf (slot) order
     const size_t nn = ctx->bvh.nodes.size();
     static_assert(sizeof(RtNode4) == 64 && sizeof(RtTriGeom) == 64, "records are 64 bytes");
-    if (nn + (size_t)nt >= (1ull << 28)) return fail("rt_commit: more than 2^28 BVH records");
-    img.records.resize(nn + (size_t)nt);
+    // (one record per SLOT: a large triangle that was cut into pieces before the build owns one slot per piece, rt_bvh.cpp)
+    const size_t ns = ctx->bvh.order.size();
+    if (nn + ns >= (1ull << 28) || ns >= (1ull << 27)) return fail("rt_commit: more than 2^28 BVH records");
+    img.records.resize(nn + ns);
     if (nn) std::memcpy(img.records.data(), ctx->bvh.nodes.data(), nn * sizeof(RtNode4));
     RtTriGeom *geom = reinterpret_cast<RtTriGeom *>(img.records.data() + nn);
-    img.shade.resize((size_t)nt);
+    img.shade.resize(ns);
     // (one contiguous piece of the slots per host thread: every record is a gather from the caller's arrays, 2.6 s on one
     // thread for 50 M triangles)
     auto assemble = [&](size_t slot0, size_t slot1) {
@@ -458,7 +460,7 @@ int commitHost(rt_context *ctx, CommitImage &img) {
     };
     {
         auto *fnp = &assemble;
-        rtParallelFor((size_t)nt, [](size_t a, size_t e, void *arg) { (*static_cast<decltype(fnp)>(arg))(a, e); }, fnp);
+        rtParallelFor(ns, [](size_t a, size_t e, void *arg) { (*static_cast<decltype(fnp)>(arg))(a, e); }, fnp);
     }
     const double t3 = nowMs();
     ctx->commit_stats = rt_commit_stats{};
@@ -514,7 +516,7 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     d.lights = ctx->d_lights.p;
     std::memcpy(d.ambient, src->ambient, 12);
     d.n_nodes = (int)nn;
-    d.n_tris = (int)nt;
+    d.n_tris = (int)img.shade.size();  // triangle SLOTS (>= triangles: pre-split pieces)
     d.n_spheres = (int)img.units.size();
     d.n_planes = (int)src->planes.size();
     d.n_lights = (int)src->lights.size();
@@ -702,10 +704,18 @@ int rt_bvh_check(int64_t n, const float *v0, const float *v1, const float *v2, i
     mix(bvh.nodes.data(), bvh.nodes.size() * sizeof(RtNode4));
     mix(bvh.nodes_p.data(), bvh.nodes_p.size() * sizeof(RtNodeP));
     mix(bvh.order.data(), bvh.order.size() * sizeof(uint32_t));
-    // containment: walking down from the root, every triangle must lie inside the decoded (quantised) box and the
-    // float box of every child slot above it, and every triangle must be reached exactly once
+    // containment: walking down from the root, every slot's piece of its triangle must lie inside the decoded (quantised)
+    // box and the float box of every child slot above it.  A triangle may own several slots (large triangles are cut into
+    // pieces before the build, rt_bvh.cpp): what must hold is that the pieces' boxes together cover it -- checked on 16
+    // points of every triangle (corners, edge midpoints, centroid, interior points): each must lie inside the box chain of
+    // at least one of the triangle's slots -- and that every slot is reached exactly once.
     int64_t bad = 0;
-    std::vector<uint8_t> seen((size_t)n, 0);
+    static const double kBary[16][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {.5, .5, 0}, {0, .5, .5}, {.5, 0, .5}, {1 / 3., 1 / 3., 1 / 3.},
+                                         {.6, .2, .2}, {.2, .6, .2}, {.2, .2, .6}, {.8, .1, .1}, {.1, .8, .1}, {.1, .1, .8},
+                                         {.45, .45, .1}, {.1, .45, .45}, {.45, .1, .45}};
+    std::vector<uint16_t> covered((size_t)n, 0);
+    std::vector<uint8_t> seen(bvh.order.size(), 0);
+    if ((int64_t)bvh.order.size() < n || bvh.references != (int64_t)bvh.order.size()) bad++;
     const uint32_t nn = (uint32_t)bvh.nodes.size();
     struct Item { uint32_t ref; float lo[3], hi[3]; };
     std::vector<Item> stack;
@@ -717,13 +727,21 @@ int rt_bvh_check(int64_t n, const float *v0, const float *v1, const float *v2, i
         if (it.ref & 0x80000000u) {
             const uint32_t first = (it.ref & 0x0FFFFFFFu) - nn, cnt = ((it.ref >> 28) & 7u) + 1u;
             for (uint32_t s = first; s < first + cnt; s++) {
-                if (s >= (uint32_t)n) { bad++; continue; }
+                if (s >= (uint32_t)bvh.order.size()) { bad++; continue; }
                 const uint32_t t = bvh.order[s];
-                seen[t]++;
+                if (t >= (uint32_t)n) { bad++; continue; }
+                seen[s]++;
                 const float *vs[3] = {v0 + 3 * (size_t)t, v1 + 3 * (size_t)t, v2 + 3 * (size_t)t};
-                for (int v = 0; v < 3; v++)
-                    for (int ax = 0; ax < 3; ax++)
-                        if (vs[v][ax] < it.lo[ax] || vs[v][ax] > it.hi[ax]) bad++;
+                for (int k = 0; k < 16; k++) {
+                    bool in = true;
+                    for (int ax = 0; ax < 3; ax++) {
+                        const double x = kBary[k][0] * vs[0][ax] + kBary[k][1] * vs[1][ax] + kBary[k][2] * vs[2][ax];
+                        // (the point is a rounded combination of the corners: a box face it sits on may miss it by an ulp)
+                        const double tol = 4e-7 * std::fmax(1e-3, std::fmax(std::fabs(vs[0][ax]), std::fmax(std::fabs(vs[1][ax]), std::fabs(vs[2][ax]))));
+                        if (x < it.lo[ax] - tol || x > it.hi[ax] + tol) in = false;
+                    }
+                    if (in) covered[t] |= (uint16_t)(1u << k);
+                }
             }
             continue;
         }
@@ -747,7 +765,9 @@ int rt_bvh_check(int64_t n, const float *v0, const float *v1, const float *v2, i
         }
     }
     for (int64_t t = 0; t < n; t++)
-        if (seen[t] != 1) bad++;
+        if (covered[t] != 0xFFFFu) bad++;
+    for (uint8_t c : seen)
+        if (c != 1) bad++;
     if (n_nodes) *n_nodes = (int64_t)bvh.nodes.size();
     if (hash) *hash = h;
     if (violations) *violations = bad;

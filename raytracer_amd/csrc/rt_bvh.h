@@ -7,7 +7,9 @@
 struct RtBvh {
     std::vector<RtNode4> nodes;   // 4-wide quantised nodes, root = node 0 (rt_types.h: RtNode4)
     std::vector<RtNodeP> nodes_p; // the same nodes with float child boxes (packet kernels)
-    std::vector<uint32_t> order;  // slot -> input triangle index (triangles are re-ordered into leaf order)
+    std::vector<uint32_t> order;  // slot -> input triangle index, in leaf order; a large triangle that was cut into pieces
+                                  // before the build (rt_bvh.cpp: presplit) owns several slots
+    int64_t references = 0;       // = order.size(): triangles + the pieces pre-splitting added
     uint32_t root_ref = 0xFFFFFFFFu;  // reference word of the root: node 0, or a leaf when the scene has <= 4 triangles
     int depth = 0;                // maximum depth of the 4-wide tree
     int max_stack = 0;            // stack entries a near-first walk can need: max over paths of sum(children - 1)

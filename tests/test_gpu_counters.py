@@ -37,7 +37,9 @@ def test_node_and_triangle_counters_equal_the_cpu_walk(monkeypatch):
     r = Renderer(0).set_scene(scene)
     nodes, order = r.get_bvh()
     info = r.get_bvh_info()
-    assert len(order) == scene.n_triangles and info["root_ref"] == 0 and info["bound"] > 0
+    # (slots >= triangles: large triangles are cut into pieces before the build and own one slot per piece)
+    assert len(order) >= scene.n_triangles and set(order.tolist()) == set(range(scene.n_triangles))
+    assert info["root_ref"] == 0 and info["bound"] > 0
     oracle = Oracle(scene)
     g = load_golden("rays_competition")
     rays = np.ascontiguousarray(g["rays"][:1536], np.float32)       # primary + bounce + shadow-like rays of the fixture
