@@ -482,8 +482,34 @@ void clipPoly(const SplitRef &in, int axis, double s, int side, SplitRef &out) {
         out.box.mx[k] = std::fmin(out.box.mx[k], in.box.mx[k]);
     }
 }
-// replaces the largest boxes of `prims` by the boxes of their pieces; returns the number of references added
-size_t presplit(std::vector<Prim> &prims, const float *v0, const float *v1, const float *v2, double budget_frac, double min_ratio) {
+// Cuts piece `cur` until its box is down to `floor_area` (or 16 cuts deep); fn(piece) for every final piece, in a fixed
+// (depth-first, low side first) order.  A cut that only grazes the piece leaves it whole.
+template <class F>
+void splitPiece(const SplitRef &cur, double floor_area, int depth, F &fn) {
+    const float area = cur.box.halfArea();
+    if (!std::isfinite(area) || !((double)area > floor_area) || depth >= 16) return fn(cur);
+    int axis = 0;
+    float ext = -1.0f;
+    for (int k = 0; k < 3; k++)
+        if (cur.box.mx[k] - cur.box.mn[k] > ext) {
+            ext = cur.box.mx[k] - cur.box.mn[k];
+            axis = k;
+        }
+    if (!(ext > 0)) return fn(cur);
+    const double s = 0.5 * ((double)cur.box.mn[axis] + (double)cur.box.mx[axis]);
+    SplitRef lo, hi;
+    clipPoly(cur, axis, s, 0, lo);
+    clipPoly(cur, axis, s, 1, hi);
+    if (lo.nv < 3 || hi.nv < 3) return fn(cur);
+    splitPiece(lo, floor_area, depth + 1, fn);
+    splitPiece(hi, floor_area, depth + 1, fn);
+}
+// Replaces the boxes of the large triangles of `prims` by the boxes of their pieces; returns the number of references
+// added.  A piece is cut while its box's surface exceeds min_ratio x the average triangle box; if that would add more than
+// budget_frac x n references the floor is raised (x 1.5 at a time) until it does not.  Every triangle is cut on its own: two
+// parallel passes (count, then write: the first piece keeps the triangle's slot, the others follow the n triangles in
+// triangle order), the same references for any thread count.
+size_t presplit(std::vector<Prim> &prims, const float *v0, const float *v1, const float *v2, double budget_frac, double min_ratio, int threads) {
     const size_t n = prims.size();
     double sum = 0.0;
     size_t finite = 0;
@@ -495,69 +521,64 @@ size_t presplit(std::vector<Prim> &prims, const float *v0, const float *v1, cons
         }
     }
     if (!finite || !(sum > 0)) return 0;
-    const double floor_area = min_ratio * sum / (double)finite;
+    double floor_area = min_ratio * sum / (double)finite;
     const size_t budget = (size_t)(budget_frac * (double)n) + 16;
-    // candidates: boxes above the floor, largest first (a heap keyed by the box's surface)
-    std::vector<SplitRef> refs;
-    struct Key { float area; uint32_t ref; };
-    auto less = [](const Key &a, const Key &b) { return a.area < b.area || (a.area == b.area && a.ref > b.ref); };
-    std::vector<Key> heap;
-    std::vector<uint32_t> home;  // ref -> index in prims of the slot it currently owns
-    for (size_t t = 0; t < n; t++) {
-        const float a = prims[t].box.halfArea();
-        if (!std::isfinite(a) || !((double)a > floor_area)) continue;
-        SplitRef r;
+    auto whole = [&](size_t t, SplitRef &r) {
         r.nv = 3;
         r.tri = (uint32_t)t;
         r.box = prims[t].box;
         const float *vs[3] = {v0 + 3 * t, v1 + 3 * t, v2 + 3 * t};
         for (int i = 0; i < 3; i++)
             for (int k = 0; k < 3; k++) r.v[i][k] = (double)vs[i][k];
-        heap.push_back(Key{a, (uint32_t)refs.size()});
-        home.push_back((uint32_t)t);
-        refs.push_back(r);
-    }
-    std::make_heap(heap.begin(), heap.end(), less);
-    size_t added = 0;
-    auto setPrim = [&](Prim &p, const SplitRef &r) {
-        p.box = r.box;
-        for (int k = 0; k < 3; k++) p.c[k] = 0.5f * (r.box.mn[k] + r.box.mx[k]);
-        p.idx = r.tri;
     };
-    while (!heap.empty() && added < budget) {
-        std::pop_heap(heap.begin(), heap.end(), less);
-        const Key top = heap.back();
-        heap.pop_back();
-        if (!((double)top.area > floor_area)) break;
-        const SplitRef cur = refs[top.ref];
-        int axis = 0;
-        float ext = -1.0f;
-        for (int k = 0; k < 3; k++)
-            if (cur.box.mx[k] - cur.box.mn[k] > ext) {
-                ext = cur.box.mx[k] - cur.box.mn[k];
-                axis = k;
+    std::vector<uint32_t> extra(n + 1, 0);  // pieces beyond the first, per triangle; then their first slot
+    size_t added = 0;
+    for (int attempt = 0; attempt < 64; attempt++) {
+        parallelRange(0, n, threads, [&](int, size_t a, size_t e) {
+            for (size_t t = a; t < e; t++) {
+                const float ar = prims[t].box.halfArea();
+                uint32_t pieces = 1;
+                if (std::isfinite(ar) && (double)ar > floor_area) {
+                    SplitRef r;
+                    whole(t, r);
+                    pieces = 0;
+                    auto count = [&](const SplitRef &) { pieces++; };
+                    splitPiece(r, floor_area, 0, count);
+                }
+                extra[t] = pieces - 1;
             }
-        if (!(ext > 0)) continue;
-        const double s = 0.5 * ((double)cur.box.mn[axis] + (double)cur.box.mx[axis]);
-        SplitRef lo, hi;
-        clipPoly(cur, axis, s, 0, lo);
-        clipPoly(cur, axis, s, 1, hi);
-        if (lo.nv < 3 || hi.nv < 3) continue;  // the cut only grazes the piece: it stays whole
-        // the first piece keeps the slot, the second gets a new one
-        const uint32_t slot = home[top.ref];
-        refs[top.ref] = lo;
-        setPrim(prims[slot], lo);
-        heap.push_back(Key{lo.box.halfArea(), top.ref});
-        std::push_heap(heap.begin(), heap.end(), less);
-        const uint32_t nr = (uint32_t)refs.size();
-        refs.push_back(hi);
-        home.push_back((uint32_t)prims.size());
-        prims.emplace_back();
-        setPrim(prims.back(), hi);
-        heap.push_back(Key{hi.box.halfArea(), nr});
-        std::push_heap(heap.begin(), heap.end(), less);
-        added++;
+        });
+        added = 0;
+        for (size_t t = 0; t < n; t++) added += extra[t];
+        if (added <= budget) break;
+        floor_area *= 1.5;
     }
+    if (!added || added > budget) return 0;
+    size_t at = n;
+    for (size_t t = 0; t < n; t++) {  // exclusive scan: where a triangle's further pieces go
+        const uint32_t c = extra[t];
+        extra[t] = (uint32_t)at;
+        at += c;
+    }
+    prims.resize(n + added);
+    Prim *P = prims.data();
+    parallelRange(0, n, threads, [&](int, size_t a, size_t e) {
+        for (size_t t = a; t < e; t++) {
+            const float ar = P[t].box.halfArea();
+            if (!(std::isfinite(ar) && (double)ar > floor_area)) continue;
+            SplitRef r;
+            whole(t, r);
+            uint32_t k = 0, next = extra[t];
+            auto write = [&](const SplitRef &pc) {
+                Prim &p = k == 0 ? P[t] : P[next++];
+                k++;
+                p.box = pc.box;
+                for (int c = 0; c < 3; c++) p.c[c] = 0.5f * (pc.box.mn[c] + pc.box.mx[c]);
+                p.idx = pc.tri;
+            };
+            splitPiece(r, floor_area, 0, write);
+        }
+    });
     return added;
 }
 
@@ -587,16 +608,18 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
             pr.idx = (uint32_t)t;
         }
     });
-    // large triangles are cut into pieces first (above): scenes of up to 4 Mi triangles, at most a quarter more references
+    // large triangles are cut into pieces first (above): scenes of up to 4 Mi triangles, at most twice the references
     // (RT_PRESPLIT=0 turns it off; RT_PRESPLIT_BUDGET / RT_PRESPLIT_MIN: sweep knobs)
     size_t split_added = 0;
     {
-        double budget = 0.25, min_ratio = 4.0;
-        bool on = n <= ((int64_t)1 << 22);
+        double budget = 1.0, min_ratio = 0.5;  // (competition frame: 434 ms without, 402 at ratio 4, 397 at 1, 390 at 0.5, 394 at 0.25)
+        int64_t max_tris = (int64_t)1 << 22;
+        if (const char *e = std::getenv("RT_PRESPLIT_MAX_TRIS")) max_tris = std::atoll(e);
+        bool on = n > RT_LEAF_MAX && n <= max_tris;  // (a scene that fits one leaf stays one leaf)
         if (const char *e = std::getenv("RT_PRESPLIT")) on = on && std::atoi(e) != 0;
         if (const char *e = std::getenv("RT_PRESPLIT_BUDGET")) budget = std::max(0.0, std::atof(e));
         if (const char *e = std::getenv("RT_PRESPLIT_MIN")) min_ratio = std::max(0.05, std::atof(e));
-        if (on && budget > 0) split_added = presplit(prims, v0, v1, v2, budget, min_ratio);
+        if (on && budget > 0) split_added = presplit(prims, v0, v1, v2, budget, min_ratio, threads);
     }
     const int64_t nrefs = (int64_t)prims.size();
     out.references = nrefs;
