@@ -93,11 +93,11 @@ class Hit(C.Structure):
 
 
 def kernel_source_hash():
-    """sha256 over the device-side sources: profiles/*.json carry it so that counter values are only ever attached to
-    measurements of the kernels they were collected on (bench.py)"""
+    """sha256 over the device-side sources and the BVH builder (the tree shapes every counter): profiles/*.json carry it so that
+    counter values are only ever attached to measurements of the kernels and the tree they were collected on (bench.py)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rt_kernels.hip", "rt_device.h", "rt_types.h"):
+    for f in ("rt_kernels.hip", "rt_device.h", "rt_types.h", "rt_bvh.cpp"):
         h.update(open(os.path.join(PKG_DIR, "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

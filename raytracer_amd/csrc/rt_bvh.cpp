@@ -49,7 +49,10 @@ struct Box {
     }
 };
 
-constexpr int kBins = 16;
+#ifndef RT_SAH_BINS
+#define RT_SAH_BINS 16
+#endif
+constexpr int kBins = RT_SAH_BINS;
 
 // Host threads of the build (the 50 M-triangle scene).  RT_BUILD_THREADS overrides; OMP_NUM_THREADS
 // is honoured because the GPU boxes set it to their CPU share.
