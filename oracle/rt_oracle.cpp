@@ -462,6 +462,16 @@ Hit objectIntersect(const Scene &s, const Scene::Ref &r, V3 o, V3 d) {
 }
 
 // closest, main.cpp:59-71
+// debugging aid (RO_LOG_RAYS=<file>, read once): every closest-hit ray with its result, as raw float bits, one line per ray --
+// the rays of one pixel can then be handed to rt_trace_batch one by one (scripts/gpu_r3_presplit_diff.py)
+FILE *rayLog() {
+    static FILE *f = [] {
+        const char *e = std::getenv("RO_LOG_RAYS");
+        return e && *e ? std::fopen(e, "w") : (FILE *)nullptr;
+    }();
+    return f;
+}
+
 Hit closest(const Scene &s, V3 o, V3 d, Counters &cn) {
     cn.closest++;
     Hit best;
@@ -470,6 +480,17 @@ Hit closest(const Scene &s, V3 o, V3 d, Counters &cn) {
     for (const Scene::Ref &r : s.order) {
         Hit h = objectIntersect(s, r, o, d);
         if (h.hit && h.distance < best.distance) best = h;
+    }
+    if (FILE *f = rayLog()) {
+        const float v[7] = {o.x, o.y, o.z, d.x, d.y, d.z, best.distance};
+        uint32_t b[7];
+        std::memcpy(b, v, sizeof b);
+#pragma omp critical(ro_ray_log)
+        {
+            std::fprintf(f, "%08x %08x %08x %08x %08x %08x %d %d %lld %08x\n", b[0], b[1], b[2], b[3], b[4], b[5], best.hit ? 1 : 0,
+                         best.hit ? best.object : -1, best.hit ? (long long)best.tri : -1ll, b[6]);
+            std::fflush(f);
+        }
     }
     return best;
 }
@@ -804,6 +825,9 @@ int ro_render(const ro_scene *rs, const rt_camera *cam, const rt_render_params *
     const int tiles_x = (width + tile_size - 1) / tile_size, tiles_y = (height + tile_size - 1) / tile_size;
     const int world = p->tile_world > 0 ? p->tile_world : 1;
     if (threads <= 0) threads = omp_get_max_threads();
+    int only_i = -1, only_j = -1;  // RO_ONLY_PIXEL="i,j": every other pixel stays black (debugging aid, with RO_LOG_RAYS)
+    if (const char *e = std::getenv("RO_ONLY_PIXEL"))
+        if (std::sscanf(e, "%d,%d", &only_i, &only_j) != 2) only_i = only_j = -1;
     Counters total;
     double t0 = omp_get_wtime();
 #pragma omp parallel num_threads(threads)
@@ -815,6 +839,7 @@ int ro_render(const ro_scene *rs, const rt_camera *cam, const rt_render_params *
             const int tj = tile / tiles_x, ti = tile - tj * tiles_x;
             for (int i = ti * tile_size; i < std::min(ti * tile_size + tile_size, width); i++)
                 for (int j = tj * tile_size; j < std::min(tj * tile_size + tile_size, height); j++) {
+                    if (only_i >= 0 && (i != only_i || j != only_j)) continue;  // (debugging aid, below)
                     V3 pixel = v3s(0.0f);
                     uint32_t pid = RT_PRIM_MISS;
                     for (int sample = 0; sample < spp; ++sample) {
