@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <emmintrin.h>
 #include <cstring>
 #include <atomic>
 #include <chrono>
@@ -88,8 +89,38 @@ struct Prim {
     float c[3];    // centroid of the box
     uint32_t idx;  // triangle number in the caller's order
 };
+static_assert(sizeof(Prim) == 40 && sizeof(Box) == 24, "the passes below read a Prim as three overlapping 16-byte loads");
 
-struct BuildTask { uint32_t self, lo, hi; int depth; };
+// The passes over the records (bounds, binning) are the build of a multi-million-triangle scene, and std::fmin / std::fmax
+// on three floats at a time is what they spend it on: each becomes a compare-unordered / min / blend sequence.  Four lanes at a
+// time instead -- (mn.xyz, mx.x), (mx.xyz, c.x), (c.xyz, idx): lane 3 rides along and is never read.  _mm_min_ps(v, acc) is
+// `v < acc ? v : acc`: a NaN coordinate leaves the accumulator alone exactly as fmin does (the accumulators start at +-inf
+// and can never become NaN), so the boxes -- and the tree -- are what the scalar passes gave.
+struct Box4 {
+    __m128 mn = _mm_set1_ps(INFINITY), mx = _mm_set1_ps(-INFINITY);
+    float halfArea() const {  // Box::halfArea, same operations in the same order
+        const __m128 d = _mm_sub_ps(mx, mn);
+        if ((_mm_movemask_ps(_mm_cmpge_ps(d, _mm_setzero_ps())) & 7) != 7) return 0.0f;
+        float t[4];
+        _mm_storeu_ps(t, _mm_mul_ps(d, _mm_shuffle_ps(d, d, _MM_SHUFFLE(3, 0, 2, 1))));  // dx dy, dy dz, dz dx
+        return t[0] + t[1] + t[2];
+    }
+    void store(Box &b) const {
+        float t[4];
+        _mm_storeu_ps(t, mn);
+        b.mn[0] = t[0]; b.mn[1] = t[1]; b.mn[2] = t[2];
+        _mm_storeu_ps(t, mx);
+        b.mx[0] = t[0]; b.mx[1] = t[1]; b.mx[2] = t[2];
+    }
+};
+
+struct Bounds { Box box, cbox; };  // of a node's references: their boxes, their centroids
+struct BuildTask {
+    uint32_t self, lo, hi;
+    int depth;
+    bool in_tmp, have_bounds;  // see Builder::build
+    Bounds bounds;
+};
 constexpr uint32_t kStableFrom = 1u << 17;  // nodes of at least this many references partition stably, out of place, on all threads
 
 // One builder = one node array.  The scene-level builder walks the top of the tree (its big nodes bin in parallel)
@@ -98,7 +129,7 @@ constexpr uint32_t kStableFrom = 1u << 17;  // nodes of at least this many refer
 struct Builder {
     Prim *prims = nullptr;            // the permutation being partitioned, as whole records
     Prim *tmp = nullptr;              // scratch of the same size (the big nodes partition out of place), or null
-    std::vector<RtNode> nodes;
+    RtRawVec<RtNode> nodes;
     int maxDepth = 0;
     uint32_t cutoff = 0;              // 0: build everything here
     int threads = 1;
@@ -113,27 +144,46 @@ struct Builder {
         }
     }
 
-    // builds the subtree of triangles prims[lo, hi) into node `self`
-    void build(uint32_t self, uint32_t lo, uint32_t hi, int depth) {
+    // Builds the subtree of the references [lo, hi) into node `self`.  The references stand in prims -- or, below a node that
+    // partitioned out of place (the huge nodes at the top), in tmp (in_tmp): such a node's children read where it wrote, and the
+    // first descendant small enough to partition in place copies its range back.  pre: the bounds of the range if the parent's
+    // partition pass gathered them on the way (same sets, so the same minima and maxima as a pass of its own).
+    void build(uint32_t self, uint32_t lo, uint32_t hi, int depth, bool in_tmp = false, const Bounds *pre = nullptr) {
         const uint32_t count = hi - lo;
         if (cutoff && count <= cutoff) {
-            tasks.push_back(BuildTask{self, lo, hi, depth});
+            tasks.push_back(BuildTask{self, lo, hi, depth, in_tmp, pre != nullptr, pre ? *pre : Bounds()});
             return;
         }
         maxDepth = std::max(maxDepth, depth);
+        if (in_tmp && !(tmp && count >= kStableFrom)) {
+            std::memcpy(prims + lo, tmp + lo, (size_t)count * sizeof(Prim));
+            in_tmp = false;
+        }
+        Prim *const src = in_tmp ? tmp : prims;  // where this node reads; `cur`, below: where its children do
+        Prim *cur = src;
         const int nt = count >= (1u << 17) ? threads : 1;  // only the few huge nodes at the top are worth threads
         Box box, cbox;
-        {
+        auto boundsOf = [&](size_t a, size_t e, Box &b, Box &c) {
+            Box4 b4, c4;
+            for (size_t i = a; i < e; i++) {
+                const float *p = reinterpret_cast<const float *>(src + i);
+                const __m128 cc = _mm_loadu_ps(p + 6);
+                b4.mn = _mm_min_ps(_mm_loadu_ps(p), b4.mn);
+                b4.mx = _mm_max_ps(_mm_loadu_ps(p + 3), b4.mx);
+                c4.mn = _mm_min_ps(cc, c4.mn);
+                c4.mx = _mm_max_ps(cc, c4.mx);
+            }
+            b4.store(b);
+            c4.store(c);
+        };
+        if (pre) {
+            box = pre->box;
+            cbox = pre->cbox;
+        } else if (nt == 1) {  // (nearly every node: no heap traffic)
+            boundsOf(lo, hi, box, cbox);
+        } else {
             std::vector<Box> pb(nt), pc(nt);
-            parallelRange(lo, hi, nt, [&](int t, size_t a, size_t e) {
-                Box b1, c1;
-                for (size_t i = a; i < e; i++) {
-                    b1.grow(prims[i].box);
-                    c1.grow(prims[i].c);
-                }
-                pb[t] = b1;
-                pc[t] = c1;
-            });
+            parallelRange(lo, hi, nt, [&](int t, size_t a, size_t e) { boundsOf(a, e, pb[t], pc[t]); });
             for (int t = 0; t < nt; t++) {
                 box.grow(pb[t]);
                 cbox.grow(pc[t]);
@@ -149,7 +199,19 @@ struct Builder {
         // binned SAH over the three axes, binned in one pass over the records
         float bestCost = INFINITY;
         int bestAxis = -1, bestSplit = -1;
-        struct Bins { Box box[3][kBins]; uint32_t cnt[3][kBins]; };
+        struct Bins {
+            float mn[3][kBins][4], mx[3][kBins][4];  // (four lanes per box: see Box4)
+            uint32_t cnt[3][kBins];
+            Bins() { clear(); }  // (parallelRange may start fewer threads than there are partial sets: every set starts empty)
+            void clear() {
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < kBins; b++) {
+                        _mm_storeu_ps(mn[a][b], _mm_set1_ps(INFINITY));
+                        _mm_storeu_ps(mx[a][b], _mm_set1_ps(-INFINITY));
+                    }
+                std::memset(cnt, 0, sizeof cnt);
+            }
+        };
         float cmin3[3], scale3[3];
         for (int axis = 0; axis < 3; axis++) {
             const float cext = cbox.mx[axis] - cbox.mn[axis];
@@ -157,18 +219,25 @@ struct Builder {
             scale3[axis] = cext > 0 ? kBins / cext : 0.0f;  // a flat axis lands in bin 0 and is skipped below
         }
         Bins all;
-        std::memset(all.cnt, 0, sizeof all.cnt);
+        std::vector<Bins> part(nt > 1 ? nt : 0);  // (per piece of the range; the stable partition below reads its counts again)
         {
-            std::vector<Bins> part(nt > 1 ? nt : 0);
+            // bin = clamp((int)((c - cmin) * scale), 0, kBins - 1): the clamp is done on the float (same bin for every
+            // finite product; a NaN product lands in bin 0 either way)
+            const __m128 cmin4 = _mm_setr_ps(cmin3[0], cmin3[1], cmin3[2], 0.0f), scale4 = _mm_setr_ps(scale3[0], scale3[1], scale3[2], 0.0f);
+            const __m128 zero4 = _mm_setzero_ps(), top4 = _mm_set1_ps((float)(kBins - 1));
+            const __m128 lanes3 = _mm_castsi128_ps(_mm_setr_epi32(-1, -1, -1, 0));
             parallelRange(lo, hi, nt, [&](int tid, size_t a, size_t e) {
                 Bins &p = nt > 1 ? part[tid] : all;
-                if (nt > 1) std::memset(p.cnt, 0, sizeof p.cnt);
                 for (size_t i = a; i < e; i++) {
-                    const Prim &pr = prims[i];
+                    const float *f = reinterpret_cast<const float *>(src + i);
+                    const __m128 bmn = _mm_loadu_ps(f), bmx = _mm_loadu_ps(f + 3), cc = _mm_and_ps(_mm_loadu_ps(f + 6), lanes3);  // (lane 3 = idx: a denormal as a float)
+                    const __m128 pos = _mm_min_ps(_mm_max_ps(_mm_mul_ps(_mm_sub_ps(cc, cmin4), scale4), zero4), top4);
+                    alignas(16) int bin[4];
+                    _mm_store_si128(reinterpret_cast<__m128i *>(bin), _mm_cvttps_epi32(pos));
                     for (int axis = 0; axis < 3; axis++) {
-                        int b = (int)((pr.c[axis] - cmin3[axis]) * scale3[axis]);
-                        b = std::min(std::max(b, 0), kBins - 1);
-                        p.box[axis][b].grow(pr.box);
+                        const int b = bin[axis];
+                        _mm_storeu_ps(p.mn[axis][b], _mm_min_ps(bmn, _mm_loadu_ps(p.mn[axis][b])));
+                        _mm_storeu_ps(p.mx[axis][b], _mm_max_ps(bmx, _mm_loadu_ps(p.mx[axis][b])));
                         p.cnt[axis][b]++;
                     }
                 }
@@ -176,31 +245,40 @@ struct Builder {
             for (size_t tid = 0; tid < part.size(); tid++)
                 for (int axis = 0; axis < 3; axis++)
                     for (int b = 0; b < kBins; b++) {
-                        all.box[axis][b].grow(part[tid].box[axis][b]);
+                        _mm_storeu_ps(all.mn[axis][b], _mm_min_ps(_mm_loadu_ps(part[tid].mn[axis][b]), _mm_loadu_ps(all.mn[axis][b])));
+                        _mm_storeu_ps(all.mx[axis][b], _mm_max_ps(_mm_loadu_ps(part[tid].mx[axis][b]), _mm_loadu_ps(all.mx[axis][b])));
                         all.cnt[axis][b] += part[tid].cnt[axis][b];
                     }
         }
+        // The sweeps visit the non-empty bins only: across an empty bin the boxes, the counts and so the cost are those of the
+        // bin before, and a strict `<` never takes an equal cost -- the split found is the one a sweep over all bins finds.
+        // Most nodes of the tree are small, and most of a small node's 3 x kBins bins are empty.
         for (int axis = 0; axis < 3; axis++) {
             if (!(cbox.mx[axis] - cbox.mn[axis] > 0)) continue;
-            const Box *bins = all.box[axis];
             const uint32_t *cnt = all.cnt[axis];
-            float rightArea[kBins];
+            int full[kBins], m = 0;
+            for (int b = 0; b < kBins; b++)
+                if (cnt[b]) full[m++] = b;
+            float rightArea[kBins];  // of the bins full[j..m)
             uint32_t rightCnt[kBins];
-            Box acc;
+            Box4 acc;
             uint32_t c = 0;
-            for (int b = kBins - 1; b > 0; b--) {
-                acc.grow(bins[b]);
+            for (int j = m - 1; j > 0; j--) {
+                const int b = full[j];
+                acc.mn = _mm_min_ps(_mm_loadu_ps(all.mn[axis][b]), acc.mn);
+                acc.mx = _mm_max_ps(_mm_loadu_ps(all.mx[axis][b]), acc.mx);
                 c += cnt[b];
-                rightArea[b] = acc.halfArea();
-                rightCnt[b] = c;
+                rightArea[j] = acc.halfArea();
+                rightCnt[j] = c;
             }
-            acc = Box();
+            acc = Box4();
             c = 0;
-            for (int b = 0; b < kBins - 1; b++) {
-                acc.grow(bins[b]);
+            for (int j = 0; j + 1 < m; j++) {
+                const int b = full[j];
+                acc.mn = _mm_min_ps(_mm_loadu_ps(all.mn[axis][b]), acc.mn);
+                acc.mx = _mm_max_ps(_mm_loadu_ps(all.mx[axis][b]), acc.mx);
                 c += cnt[b];
-                if (c == 0 || rightCnt[b + 1] == 0) continue;
-                const float cost = acc.halfArea() * c + rightArea[b + 1] * rightCnt[b + 1];
+                const float cost = acc.halfArea() * c + rightArea[j + 1] * rightCnt[j + 1];
                 if (cost < bestCost) {
                     bestCost = cost;
                     bestAxis = axis;
@@ -214,6 +292,8 @@ struct Builder {
             if (bestAxis < 0 || bestCost + RT_SAH_STEP_COST * box.halfArea() >= leafCost) return makeLeaf();
         }
         uint32_t mid;
+        Bounds kidBounds[2];
+        bool haveKidBounds = false;
         if (bestAxis >= 0) {
             const float cmin = cbox.mn[bestAxis], scale = kBins / (cbox.mx[bestAxis] - cbox.mn[bestAxis]);
             auto pred = [&](const Prim &t) {
@@ -223,26 +303,49 @@ struct Builder {
             };
             if (tmp && count >= kStableFrom) {
                 // The few huge nodes at the top: std::partition is one thread walking gigabytes (8 levels of the 50 M-triangle
-                // build: most of its 2.4 s).  A STABLE partition out of place instead -- count per piece, scatter, copy back,
-                // every pass on all threads -- whose result does not depend on how the range is cut into pieces, so that the
-                // tree stays the same for any thread count (which algorithm a node gets depends on its size alone).
+                // build: most of its 2.4 s).  A STABLE partition out of place instead, on all threads, whose result does not
+                // depend on how the range is cut into pieces, so that the tree stays the same for any thread count (which
+                // algorithm a node gets depends on its size alone).  ONE pass: how many of a piece go left is already known
+                // (the binning pass cut the range into the same pieces, and pred is "bin <= bestSplit" with the same
+                // arithmetic); the children read the other array instead of a copy back; and their bounds are gathered while
+                // the records pass through.  These levels are bound by memory: 6 passes over the array per level became 3.
                 const int T = std::max(1, (int)std::min<size_t>((size_t)std::max(nt, 1), std::max<size_t>(count / 65536, 1)));
                 std::vector<uint32_t> left((size_t)T + 1, 0);
-                parallelRange(lo, hi, nt, [&](int t, size_t a, size_t e) {
+                for (int t = 0; t < T; t++) {
+                    const uint32_t *cnt = nt > 1 ? part[(size_t)t].cnt[bestAxis] : all.cnt[bestAxis];
                     uint32_t c = 0;
-                    for (size_t i = a; i < e; i++) c += pred(prims[i]) ? 1u : 0u;
-                    left[(size_t)t + 1] = c;
-                });
-                for (int t = 0; t < T; t++) left[(size_t)t + 1] += left[(size_t)t];
+                    for (int b = 0; b <= bestSplit; b++) c += cnt[b];
+                    left[(size_t)t + 1] = left[(size_t)t] + c;
+                }
                 const uint32_t L = left[(size_t)T];
+                Prim *const dst = in_tmp ? prims : tmp;
+                std::vector<Bounds> kb(2 * (size_t)T);
                 parallelRange(lo, hi, nt, [&](int t, size_t a, size_t e) {
-                    Prim *dl = tmp + lo + left[(size_t)t], *dr = tmp + lo + L + ((a - lo) - left[(size_t)t]);
+                    Prim *dl = dst + lo + left[(size_t)t], *dr = dst + lo + L + ((a - lo) - left[(size_t)t]);
+                    Box4 lb, lc, rb, rc;
                     for (size_t i = a; i < e; i++) {
-                        if (pred(prims[i])) *dl++ = prims[i];
-                        else *dr++ = prims[i];
+                        const float *f = reinterpret_cast<const float *>(src + i);
+                        const __m128 bmn = _mm_loadu_ps(f), bmx = _mm_loadu_ps(f + 3), cc = _mm_loadu_ps(f + 6);
+                        if (pred(src[i])) {
+                            *dl++ = src[i];
+                            lb.mn = _mm_min_ps(bmn, lb.mn); lb.mx = _mm_max_ps(bmx, lb.mx);
+                            lc.mn = _mm_min_ps(cc, lc.mn); lc.mx = _mm_max_ps(cc, lc.mx);
+                        } else {
+                            *dr++ = src[i];
+                            rb.mn = _mm_min_ps(bmn, rb.mn); rb.mx = _mm_max_ps(bmx, rb.mx);
+                            rc.mn = _mm_min_ps(cc, rc.mn); rc.mx = _mm_max_ps(cc, rc.mx);
+                        }
                     }
+                    lb.store(kb[2 * (size_t)t].box); lc.store(kb[2 * (size_t)t].cbox);
+                    rb.store(kb[2 * (size_t)t + 1].box); rc.store(kb[2 * (size_t)t + 1].cbox);
                 });
-                parallelRange(lo, hi, nt, [&](int, size_t a, size_t e) { std::memcpy(prims + a, tmp + a, (e - a) * sizeof(Prim)); });
+                for (int t = 0; t < T; t++)
+                    for (int k = 0; k < 2; k++) {
+                        kidBounds[k].box.grow(kb[2 * (size_t)t + k].box);
+                        kidBounds[k].cbox.grow(kb[2 * (size_t)t + k].cbox);
+                    }
+                haveKidBounds = true;
+                cur = dst;
                 mid = lo + L;
             } else {
                 auto it = std::partition(prims + lo, prims + hi, pred);
@@ -253,13 +356,15 @@ struct Builder {
         }
         if (mid == lo || mid == hi) {  // degenerate: split by count (keeps depth bounded)
             mid = lo + count / 2;
+            haveKidBounds = false;
         }
         // deep trees cost LDS stack: past a budget fall back to median splits, which bound the remaining depth
         if (depth >= 40 && bestAxis >= 0) {
             const int axis = bestAxis;
             mid = lo + count / 2;
-            std::nth_element(prims + lo, prims + mid, prims + hi,
+            std::nth_element(cur + lo, cur + mid, cur + hi,
                              [&](const Prim &a, const Prim &b) { return a.c[axis] < b.c[axis]; });
+            haveKidBounds = false;
         }
         const uint32_t left = (uint32_t)nodes.size();
         nodes.emplace_back();
@@ -267,8 +372,8 @@ struct Builder {
         std::memset(&nodes[left], 0, 2 * sizeof(RtNode));
         nodes[self].a = left;
         nodes[self].b = 0;
-        build(left, lo, mid, depth + 1);
-        build(left + 1, mid, hi, depth + 1);
+        build(left, lo, mid, depth + 1, cur == tmp, haveKidBounds ? &kidBounds[0] : nullptr);
+        build(left + 1, mid, hi, depth + 1, cur == tmp, haveKidBounds ? &kidBounds[1] : nullptr);
     }
 };
 
@@ -305,10 +410,10 @@ void refOrder(const float *v0, const float *v1, const float *v2, std::vector<uin
 // close); (2) quantise the child boxes and write both node forms.  The tree does not depend on the thread count.
 // (Round 2 emitted the nodes depth first on one thread and renumbered afterwards: 2.8 s of the 50 M-triangle commit.)
 struct Collapser {
-    const std::vector<RtNode> &bn;
+    const RtRawVec<RtNode> &bn;
     int threads = 1;
-    std::vector<RtNode4> out;
-    std::vector<RtNodeP> outP;  // same indices as `out`
+    RtRawVec<RtNode4> out;        // (fill() writes every byte of both forms)
+    RtRawVec<RtNodeP> outP;       // same indices as `out`
     int maxDepth = 0, maxStack = 0;
     float bound = 0.0f;
 
@@ -410,9 +515,9 @@ struct Collapser {
     void run(uint32_t root) {
         out.reserve(bn.size() / 2 + 1);   // (every 4-wide node stands for at least one binary inner node)
         outP.reserve(bn.size() / 2 + 1);
-        std::vector<Item> level{Item{root, 0}}, nextLevel;
-        std::vector<Kids> kids;
-        std::vector<uint32_t> firstChild;
+        RtRawVec<Item> level{Item{root, 0}}, nextLevel;
+        RtRawVec<Kids> kids;
+        RtRawVec<uint32_t> firstChild;
         size_t base = 0;
         for (int depth = 1; !level.empty(); depth++) {
             const size_t n = level.size();
@@ -540,7 +645,7 @@ void splitPiece(const SplitRef &cur, double floor_area, int depth, F &fn) {
 // budget_frac x n references the floor is raised (x 1.5 at a time) until it does not.  Every triangle is cut on its own: two
 // parallel passes (count, then write: the first piece keeps the triangle's slot, the others follow the n triangles in
 // triangle order), the same references for any thread count.
-size_t presplit(std::vector<Prim> &prims, const float *v0, const float *v1, const float *v2, double budget_frac, double min_ratio, int threads) {
+size_t presplit(RtRawVec<Prim> &prims, const float *v0, const float *v1, const float *v2, double budget_frac, double min_ratio, int threads) {
     const size_t n = prims.size();
     double sum = 0.0;
     size_t finite = 0;
@@ -628,10 +733,11 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     const bool verbose = std::getenv("RT_VERBOSE") != nullptr;
     const double t0 = nowSeconds();
     const int threads = buildThreads();
-    std::vector<Prim> prims((size_t)n);
+    RtRawVec<Prim> prims((size_t)n);
     parallelRange(0, (size_t)n, threads, [&](int, size_t a, size_t e) {
         for (size_t t = a; t < e; t++) {
             Prim &pr = prims[t];
+            pr.box = Box();
             pr.box.grow(v0 + 3 * t);
             pr.box.grow(v1 + 3 * t);
             pr.box.grow(v2 + 3 * t);
@@ -682,28 +788,40 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
                     w.tmp = b.tmp;  // (tasks own disjoint ranges of both arrays)
                     w.nodes.resize(1);
                     std::memset(w.nodes.data(), 0, sizeof(RtNode));
-                    w.build(0, b.tasks[k].lo, b.tasks[k].hi, b.tasks[k].depth);
+                    w.build(0, b.tasks[k].lo, b.tasks[k].hi, b.tasks[k].depth, b.tasks[k].in_tmp, b.tasks[k].have_bounds ? &b.tasks[k].bounds : nullptr);
                 }
             });
         for (std::thread &th : pool) th.join();
-        for (size_t k = 0; k < sub.size(); k++) {  // append: local node j >= 1 becomes global node base + j - 1
-            const uint32_t base = (uint32_t)b.nodes.size();
-            auto fix = [&](RtNode nd) {
-                if (nd.b == 0) nd.a += base - 1;
-                return nd;
-            };
-            b.nodes[b.tasks[k].self] = fix(sub[k].nodes[0]);
-            for (size_t j = 1; j < sub[k].nodes.size(); j++) b.nodes.push_back(fix(sub[k].nodes[j]));
-            b.maxDepth = std::max(b.maxDepth, sub[k].maxDepth);
-            std::vector<RtNode>().swap(sub[k].nodes);
-        }
+        // append, in task order: local node j >= 1 of subtree k becomes global node base[k] + j - 1
+        std::vector<size_t> base(sub.size() + 1);
+        base[0] = b.nodes.size();
+        for (size_t k = 0; k < sub.size(); k++) base[k + 1] = base[k] + sub[k].nodes.size() - 1;
+        b.nodes.resize(base[sub.size()]);
+        next = 0;
+        pool.clear();
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back([&] {
+                for (size_t k; (k = next.fetch_add(1)) < sub.size();) {
+                    const uint32_t shift = (uint32_t)base[k] - 1;
+                    auto fix = [&](RtNode nd) {
+                        if (nd.b == 0) nd.a += shift;
+                        return nd;
+                    };
+                    b.nodes[b.tasks[k].self] = fix(sub[k].nodes[0]);
+                    RtNode *dst = b.nodes.data() + base[k] - 1;
+                    for (size_t j = 1; j < sub[k].nodes.size(); j++) dst[j] = fix(sub[k].nodes[j]);
+                    RtRawVec<RtNode>().swap(sub[k].nodes);
+                }
+            });
+        for (std::thread &th : pool) th.join();
+        for (size_t k = 0; k < sub.size(); k++) b.maxDepth = std::max(b.maxDepth, sub[k].maxDepth);
     }
     const double t2 = nowSeconds();
     out.order.resize((size_t)nrefs);
     parallelRange(0, (size_t)nrefs, threads, [&](int, size_t a, size_t e) {
         for (size_t i = a; i < e; i++) out.order[i] = prims[i].idx;
     });
-    std::vector<Prim>().swap(prims);
+    RtRawVec<Prim>().swap(prims);
     out.binary_nodes = (int64_t)b.nodes.size();
     const RtNode &root = b.nodes[1];
     if (root.b) {  // the whole scene is one leaf
@@ -724,12 +842,14 @@ void rtBuildBvh(int64_t n, const float *v0, const float *v1, const float *v2, Rt
     }
     // triangle records follow the nodes in the record array: rebase the leaf references
     const uint32_t base = (uint32_t)out.nodes.size();
-    for (size_t i = 0; i < out.nodes.size(); i++)
-        for (int k = 0; k < 4; k++) {
-            uint32_t &ch = out.nodes[i].child[k];
-            if (ch != 0xFFFFFFFFu && (ch & 0x80000000u)) ch += base;
-            out.nodes_p[i].child[k] = ch;
-        }
+    parallelRange(0, out.nodes.size(), threads, [&](int, size_t a, size_t e) {
+        for (size_t i = a; i < e; i++)
+            for (int k = 0; k < 4; k++) {
+                uint32_t &ch = out.nodes[i].child[k];
+                if (ch != 0xFFFFFFFFu && (ch & 0x80000000u)) ch += base;
+                out.nodes_p[i].child[k] = ch;
+            }
+    });
     if (out.root_ref & 0x80000000u) out.root_ref += base;
     if (verbose)
         std::fprintf(stderr, "[rt_bvh] %lld triangles (+ %zu references from pre-splitting), %d threads: top %.2f s, subtrees %.2f s (%zu tasks), collapse+quantise+renumber %.2f s\n",

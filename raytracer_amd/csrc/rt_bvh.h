@@ -1,12 +1,26 @@
 // rt_bvh.h -- host BVH builder interface (rt_bvh.cpp).
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <new>
+#include <utility>
 #include <vector>
 #include "rt_types.h"
 
+// Vectors whose resize() leaves the new elements alone: the arrays of a 50 M-triangle build are gigabytes, written once by the
+// threads that fill them -- a vector's own value-initialisation is one thread touching every page first (it was a quarter of
+// the build).  Only for element types that are written before they are read.
+template <class T>
+struct RtRawAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = RtRawAlloc<U>; };
+    template <class U> void construct(U *) noexcept {}
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using RtRawVec = std::vector<T, RtRawAlloc<T>>;
+
 struct RtBvh {
-    std::vector<RtNode4> nodes;   // 4-wide quantised nodes, root = node 0 (rt_types.h: RtNode4)
-    std::vector<RtNodeP> nodes_p; // the same nodes with float child boxes (packet kernels)
+    RtRawVec<RtNode4> nodes;      // 4-wide quantised nodes, root = node 0 (rt_types.h: RtNode4)
+    RtRawVec<RtNodeP> nodes_p;    // the same nodes with float child boxes (packet kernels)
     std::vector<uint32_t> order;  // slot -> input triangle index, in leaf order; a large triangle that was cut into pieces
                                   // before the build (rt_bvh.cpp: presplit) owns several slots
     int64_t references = 0;       // = order.size(): triangles + the pieces pre-splitting added
