@@ -53,6 +53,7 @@ def lib():
         L.ro_eval_texture.argtypes = [VP, C.c_int32, C.c_int64, VP, VP]
         L.ro_eval_perlin.argtypes = [C.c_int64, VP, VP]
         L.ro_reference_order.argtypes = [VP, VP]
+        L.ro_set_ray_log.argtypes = [C.c_char_p]
         L.ro_walk_counts.argtypes = [VP, C.c_uint32, C.c_float, C.c_int64, VP, VP, VP, VP, C.c_int64, VP, VP, VP, VP, VP]
         _lib = L
     return _lib
@@ -60,6 +61,23 @@ def lib():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def set_ray_log(path):
+    """every closest-hit ray the oracle traces from now on goes to `path` (None stops); see read_ray_log"""
+    if lib().ro_set_ray_log(path.encode() if path else None):
+        raise RuntimeError(f"cannot write {path}")
+
+
+def read_ray_log(path):
+    """-> rays (n, 6) float32, hit (n,), object (n,), triangle (n,; scene numbering), distance (n,) float32 -- exact bits"""
+    raw = np.loadtxt(path, dtype=str, ndmin=2)
+    if raw.size == 0:
+        z = np.zeros(0, np.int64)
+        return np.zeros((0, 6), np.float32), z, z, z, np.zeros(0, np.float32)
+    rays = np.array([[int(x, 16) for x in r[:6]] for r in raw], np.uint32).view(np.float32)
+    dist = np.array([int(r[9], 16) for r in raw], np.uint32).view(np.float32)
+    return rays, raw[:, 6].astype(np.int64), raw[:, 7].astype(np.int64), raw[:, 8].astype(np.int64), dist
 
 
 def eval_perlin(points):

@@ -462,15 +462,11 @@ Hit objectIntersect(const Scene &s, const Scene::Ref &r, V3 o, V3 d) {
 }
 
 // closest, main.cpp:59-71
-// debugging aid (RO_LOG_RAYS=<file>, read once): every closest-hit ray with its result, as raw float bits, one line per ray --
-// the rays of one pixel can then be handed to rt_trace_batch one by one (scripts/gpu_r3_presplit_diff.py)
-FILE *rayLog() {
-    static FILE *f = [] {
-        const char *e = std::getenv("RO_LOG_RAYS");
-        return e && *e ? std::fopen(e, "w") : (FILE *)nullptr;
-    }();
-    return f;
-}
+// Test aid (ro_set_ray_log): every closest-hit ray with its result, as raw float bits, one line per ray -- the rays a frame
+// really traces (primary rays and every bounce) can then be handed to rt_trace_batch one by one
+// (tests/test_gpu_raylog.py, scripts/gpu_r3_pixel_rays.py).
+FILE *g_rayLog = nullptr;
+FILE *rayLog() { return g_rayLog; }
 
 Hit closest(const Scene &s, V3 o, V3 d, Counters &cn) {
     cn.closest++;
@@ -489,7 +485,6 @@ Hit closest(const Scene &s, V3 o, V3 d, Counters &cn) {
         {
             std::fprintf(f, "%08x %08x %08x %08x %08x %08x %d %d %lld %08x\n", b[0], b[1], b[2], b[3], b[4], b[5], best.hit ? 1 : 0,
                          best.hit ? best.object : -1, best.hit ? (long long)best.tri : -1ll, b[6]);
-            std::fflush(f);
         }
     }
     return best;
@@ -808,6 +803,17 @@ ro_scene *ro_create(const ro_scene_desc *d) {
 
 void ro_destroy(ro_scene *s) { delete s; }
 
+// path: file to (over)write with one line per closest-hit ray from now on; NULL or "" stops logging
+int ro_set_ray_log(const char *path) {
+    if (g_rayLog) std::fclose(g_rayLog);
+    g_rayLog = nullptr;
+    if (path && *path) {
+        g_rayLog = std::fopen(path, "w");
+        if (!g_rayLog) return 1;
+    }
+    return 0;
+}
+
 int ro_render(const ro_scene *rs, const rt_camera *cam, const rt_render_params *p, uint8_t *out_rgb8,
               int32_t *out_rgb8_i32, float *out_rgbf, uint32_t *out_primid, rt_stats *stats, int threads) {
     const Scene &s = rs->s;
@@ -825,7 +831,7 @@ int ro_render(const ro_scene *rs, const rt_camera *cam, const rt_render_params *
     const int tiles_x = (width + tile_size - 1) / tile_size, tiles_y = (height + tile_size - 1) / tile_size;
     const int world = p->tile_world > 0 ? p->tile_world : 1;
     if (threads <= 0) threads = omp_get_max_threads();
-    int only_i = -1, only_j = -1;  // RO_ONLY_PIXEL="i,j": every other pixel stays black (debugging aid, with RO_LOG_RAYS)
+    int only_i = -1, only_j = -1;  // RO_ONLY_PIXEL="i,j": every other pixel stays black (debugging aid, with ro_set_ray_log)
     if (const char *e = std::getenv("RO_ONLY_PIXEL"))
         if (std::sscanf(e, "%d,%d", &only_i, &only_j) != 2) only_i = only_j = -1;
     Counters total;

@@ -58,6 +58,10 @@ int ro_eval_perlin(int64_t n, const float *p, float *out);
 /* rank[t] = position of triangle t in the order the reference's per-mesh BVH hands candidates out
  * (MeshLoader.h:265-284: left subtree before right, file order inside a leaf), meshes in object order */
 int ro_reference_order(const ro_scene *s, uint32_t *rank);
+/* test aid: from now on every closest-hit ray (primary rays and bounces of ro_render / ro_trace_batch) is written to `path`,
+ * one line of hex float bits per ray: origin, direction, then hit, object, triangle (scene numbering, -1 = none), distance.
+ * NULL or "" stops.  Process-wide; not for concurrent scenes. */
+int ro_set_ray_log(const char *path);
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
-"""The closest-hit rays of ONE pixel, from the oracle (RO_ONLY_PIXEL / RO_LOG_RAYS), traced one by one through rt_trace_batch with
-and without pre-splitting: which ray's hit differs, and what the reference's own walk (the oracle) says about it."""
+"""The closest-hit rays of ONE pixel, from the oracle (RO_ONLY_PIXEL + ro_set_ray_log), traced one by one through rt_trace_batch
+with and without pre-splitting: which ray's hit differs, and what the reference's own walk (the oracle) says about it.
+usage: gpu_r3_pixel_rays.py i j spp [cpu]"""
 import os
 import sys
 
@@ -11,19 +12,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 i, j, spp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 log = os.path.join(ROOT, "gpurun_out", f"pixel_{i}_{j}.rays")
 os.makedirs(os.path.dirname(log), exist_ok=True)
-os.environ["RO_LOG_RAYS"] = log
 os.environ["RO_ONLY_PIXEL"] = f"{i},{j}"
 from conftest import get_scene  # noqa: E402
-from oracle.binding import Oracle  # noqa: E402
+from oracle.binding import Oracle, read_ray_log, set_ray_log  # noqa: E402
 
 scene = get_scene("competition", False)
 o = Oracle(scene)
+set_ray_log(log)
 o.render(1280, 720, spp=spp, max_depth=3, threads=1)
-rows = [l.split() for l in open(log)]
-rays = np.array([[int(x, 16) for x in r[:6]] for r in rows], np.uint32).view(np.float32)
-ohit = np.array([int(r[6]) for r in rows])
-otri = np.array([int(r[8]) for r in rows])
-odist = np.array([int(r[9], 16) for r in rows], np.uint32).view(np.float32)
+set_ray_log(None)
+rays, ohit, _, otri, odist = read_ray_log(log)
 print(f"pixel ({i},{j}): {len(rays)} closest-hit rays, {ohit.sum()} hits")
 if len(sys.argv) > 4 and sys.argv[4] == "cpu":
     sys.exit(0)
