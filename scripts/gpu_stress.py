@@ -16,7 +16,7 @@ print(f"{W}x{H} @{SPP}spp: {st['ms_total']:.1f} ms, {rays / st['ms_total'] / 1e3
       f"nodes {st['bvh_nodes']} depth {st['bvh_depth']} max_stack {st['bvh_max_stack']}")
 if os.environ.get("RT_STRESS_DETAIL", "1") != "0":
     t = r.render(W, H, spp=SPP, want=(), collect_stats=2)["stats"]
-    print("kernel ms:", {k: round(t[k], 1) for k in ("ms_gen", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total")}, flush=True)
+    print("kernel ms:", {k: round(t[k], 1) for k in ("ms_gen", "ms_trace", "ms_packet", "ms_closest", "ms_shade", "ms_any", "ms_resolve", "ms_total") if t.get(k, 0) > 0.05}, flush=True)
     c = r.render(W, H, spp=SPP, want=(), collect_stats=1)["stats"]
     print(f"records per closest ray: nodes {c['nodes_visited'] / c['rays_closest']:.2f} tris {c['tris_tested'] / c['rays_closest']:.2f}; "
           f"per shadow ray: nodes {c['nodes_visited_any'] / c['rays_shadow']:.2f} tris {c['tris_tested_any'] / c['rays_shadow']:.2f}; "
