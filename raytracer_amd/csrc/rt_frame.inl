@@ -97,6 +97,12 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     return off;
 }
 
+// A frame's primary rays: (origin, weight) is what k_gen_primary would store for every one of them (RtQueues::primA)
+void rtImplyPrimaryOrigin(RtQueues &q, const RtFrameDev &f) {
+    q.primA = make_float4(f.origin[0], f.origin[1], f.origin[2], 1.0f);
+    q.prim_implied = 1u;
+}
+
 // How a frame of `n_local` tiles is cut into chunks and what its queues hold.
 struct FramePlan {
     size_t tiles = 0, samples = 0, nchunks = 0;  // tiles / primary sample slots per chunk; chunks of the frame
@@ -529,8 +535,10 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         }
         if (ensureArena(ctx, want)) return 1;
         RtQueues q[2];
-        for (int l = 0; l < pl.lanes; l++)  // (every lane its own queues, counters and traversal spill area)
+        for (int l = 0; l < pl.lanes; l++) {  // (every lane its own queues, counters and traversal spill area)
             carveQueues(ctx->d_arena.p + (size_t)l * (pl.bytes / (size_t)pl.lanes), pl.spec, ctx->d_spill.p + (size_t)l * ctx->spill_words, q[l]);
+            rtImplyPrimaryOrigin(q[l], f);
+        }
         cfg.shade_slab = pl.z.slab;
         if (getenv("RT_VERBOSE"))
             std::fprintf(stderr, "[rt] frame: %zu chunks of %zu samples in %d lane(s) (%d in flight per lane), %s queues %.2f rays + %.2f shadow rays per sample, %.2f GB%s\n",
@@ -697,6 +705,7 @@ int renderTilesStatic(rt_context *ctx, const rt_camera *cam, const rt_render_par
                     " MiB static scratch (lower spp or max_depth, or use rt_render_tiles_device)");
     RtQueues q;
     carveQueues((unsigned char *)ctx->scratch, pl.spec, ctx->d_spill.p, q);
+    rtImplyPrimaryOrigin(q, f);
     KernelTimer kt;  // (off)
     if (enqueueFrame(ctx, cfg, f, pl, &q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, true, kt, nullptr)) return 1;
     HIPOK(hipGetLastError());

@@ -485,9 +485,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
         } else {
             invalid++;
         }
-        q.rayA[par][idx] = A;
+        // ((origin, weight) is the same for every primary ray: RtQueues::primA; the Fresnel word is only read for reflection
+        // rays with a refraction sibling)
+        if (!q.prim_implied) q.rayA[par][idx] = A;
         q.rayB[par][idx] = B;
-        q.rayR[par][idx] = 1.0f;
     }
     if (__ballot(invalid != 0)) {
         for (int off = 32; off > 0; off >>= 1) invalid += __shfl_down(invalid, off);
@@ -657,6 +658,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     constexpr uint32_t PARTS = MODE == RT_MODE_QUEUE ? RT_WORK_PARTS : 1u;
     uint32_t *work_parts = q.counters + (ANY ? RT_CNT_WORKP_ANY(par, 0) : RT_CNT_WORKP_CLOSEST(par, 0));
     const uint32_t span = n > first ? n - first : 0u;     // entries [first, n) are this launch's
+    const bool prim_here = !ANY && q.prim_implied && first < q.prim_n;  // primary rays in this queue walk: their origin is RtQueues::primA
     const uint32_t part_len = PARTS > 1 ? ((span + PARTS - 1) / PARTS + batch - 1) / batch * batch : span;
     uint32_t part = PARTS > 1 ? blockIdx.x % PARTS : 0u, parts_done = 0;  // wave-uniform
     const uint2 *items_in = q.split[round & 1];
@@ -841,6 +843,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                     ray_i = pos;
                 }
                 if (!nothing) A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
+                if (!ANY && prim_here && ray_i < q.prim_n) A = q.primA;  // (wave-uniform prim_here: only where primary rays walk per lane)
                 if (ANY && !nothing) light = q.shL[ray_i];
                 if (!ANY) B = q.rayB[buf][ray_i];
                 if (ANY && !SPLIT) nothing = __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
@@ -1014,7 +1017,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtTraceLds &tl, uint32_t roo
     RtWalk w;
     float4 A = make_float4(0.0f, 0.0f, 0.0f, 0.0f), B = make_float4(0.0f, 0.0f, 1.0f, __uint_as_float(RT_FLAG_INVALID));
     if (valid) {
-        A = q.rayA[buf][i];
+        A = q.prim_implied ? q.primA : q.rayA[buf][i];  // (packets are primary rays: i < prim_n)
         B = q.rayB[buf][i];
     }
     const uint32_t sample = __float_as_uint(B.w);
@@ -1364,7 +1367,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
         float4 A = make_float4(0, 0, 0, 0), B = make_float4(0, 0, 0, __uint_as_float(RT_FLAG_INVALID));
         if (active) {
             hrec = q.hits[i];
-            A = q.rayA[buf][i];
+            A = (q.prim_implied && i < q.prim_n) ? q.primA : q.rayA[buf][i];
             B = q.rayB[buf][i];
         }
         const uint32_t id = __float_as_uint(hrec.y);

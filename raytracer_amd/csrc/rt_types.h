@@ -201,6 +201,11 @@ struct RtQueues {
     // this iteration (set by the host per launch): entries [0, prim_n) of the current ray queue are the primary rays of the
     // chunk that enters the pipeline -- level 0, entry k belongs to ring sample prim_sample0 + k
     uint32_t prim_n, prim_sample0;
+    // A frame's primary rays all start at the camera with weight 1: with prim_implied their (origin, weight) words are
+    // neither written nor read -- primA stands for rayA[..][k], k < prim_n (16 of a primary ray's 36 bytes, three times:
+    // k_gen_primary's store, the packets' load, k_shade's load).  0 for rays handed in by the host (rt_trace_batch).
+    float4 primA;
+    uint32_t prim_implied;
     uint32_t tile_stride;      // local tiles of a chunk: tile0 + k * tile_stride (tile0 = the chunk's number, stride = chunks of the frame)
     uint32_t l0_sample0;       // ring sample of the first level-0 shadow ray's chunk (the fused k_trace walks the shadow rays of
                                // iteration j next to the primary rays of chunk j + 1, which prim_n / prim_sample0 then describe)
