@@ -1009,7 +1009,9 @@ int ro_walk_counts(const ro_scene *rs, uint32_t root_ref, float bound, int64_t n
         const V3 oiN = oi + err, oiF = oi - err;
         std::vector<uint32_t> stack;
         uint32_t cur = s.tris.empty() ? DONE : root_ref, pend = DONE;
-        float best_t = INFINITY;
+        // (rtFarLimit, rt_kernels.hip: a ray without an analytic hit starts with the farthest distance the scene allows)
+        const float reach = 2.0f * (std::fabs(o.x) + std::fabs(o.y) + std::fabs(o.z)) + 4.0f * bound;
+        float best_t = reach * std::fmin(std::fmin(std::fabs(inv.x), std::fabs(inv.y)), std::fabs(inv.z));
         uint32_t best_id = MISS, best_rank = 0;
         int best_obj = 0x7FFFFFFF;
         uint64_t nn = 0, nt = 0;

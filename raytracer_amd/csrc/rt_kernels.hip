@@ -361,7 +361,21 @@ RT_DEV bool sphereBoxHit(const RtSphere &sp, V3 inv, V3 oi) {
     return tmin <= tmax * 1.0000005f;
 }
 
-// closest() over the analytic primitives, in scene order (ties resolved by object order, main.cpp:67)
+// No triangle of the scene is farther from a ray's origin than this, in units of the ray's parameter: every corner lies within
+// sc.bound of the coordinate origin on each axis, and 1 / max |d_k| >= 1 / |d| (rays handed in by a host need not be unit).
+// Twice what the geometry allows.
+RT_DEV float rtFarLimit(const RtSceneDev &sc, const RtWalk &w) {
+    const float reach = 2.0f * (fabsf(w.r.o.x) + fabsf(w.r.o.y) + fabsf(w.r.o.z)) + 4.0f * sc.bound;
+    return reach * fminf(fminf(fabsf(w.inv.x), fabsf(w.inv.y)), fabsf(w.inv.z));
+}
+
+// closest() over the analytic primitives, in scene order (ties resolved by object order, main.cpp:67).
+// A ray that meets none of them starts its walk with best_t = rtFarLimit instead of infinity (best_id stays MISS, and a miss is
+// reported with an infinite distance): the reference's triangle test accepts points millions of scene sizes away when a ray
+// is almost parallel to a triangle's plane (there cross(B - P, C - P) is exactly zero) -- IF its walk happens to test that
+// triangle, so which of these a ray "hit" depended on the tree, on the walk (packet boxes are exact, per-lane boxes 8-bit)
+// and on the 63 rays sharing its packet.  With the limit a ray's result is a function of the ray and the scene alone
+// (what that costs in agreement with the reference -- its own such hits, ~1 per 10^8 rays -- and buys).
 RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &w) {
     w.best_t = INFINITY;
     w.best_id = RT_ID_MISS;
@@ -387,6 +401,7 @@ RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &
             w.best_obj = pl.object;
         }
     }
+    if (w.best_id == RT_ID_MISS) w.best_t = rtFarLimit(sc, w);
 }
 // is_shadowed() after its back-face test, analytic part: any primitive with hit.distance <= dist (main.cpp:50-55)
 RT_DEV bool analyticOccluded(const RtSceneDev &sc, const RtAnalytic &an, const RtWalk &w, float dist) {
@@ -732,7 +747,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             atomicAdd(acc + 1, (unsigned long long)rtToFixed(C.y));
             atomicAdd(acc + 2, (unsigned long long)rtToFixed(C.z));
         }
-        if (!ANY) q.hits[ri] = make_float2(w.best_t, __uint_as_float(w.best_id));
+        if (!ANY) q.hits[ri] = make_float2(w.best_id == RT_ID_MISS ? INFINITY : w.best_t, __uint_as_float(w.best_id));
         fin = false;
     };
     // STATS build only: where a wave's time goes (shader clock): [0] refill cycles, [1] node-phase cycles, [2] node
@@ -1155,7 +1170,7 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtTraceLds &tl, uint32_t roo
             if (has && w.cur == RT_NODE_DONE && w.pend == RT_NODE_DONE) has = false;
         }
     }
-    if (valid) q.hits[i] = make_float2(w.best_t, __uint_as_float(w.best_id));
+    if (valid) q.hits[i] = make_float2(w.best_id == RT_ID_MISS ? INFINITY : w.best_t, __uint_as_float(w.best_id));
 }
 
 // the primary rays of the entering chunk: entries [0, q.prim_n) of ray queue `par`, 64 at a time
