@@ -35,7 +35,22 @@ def test_logged_rays_of_a_frame(name, w, h, spp, tmp_path):
     assert len(rays) >= w * h * spp
     r = Renderer(0).set_scene(scene)
     _, hits, _, st = r.trace_batch(rays, depth=0, want_shadow=False)
+    # the same rays as primary rays of trace_ray at full depth: colour, and is_shadowed of the first hit towards every light
+    sub = rays[:: max(1, len(rays) // 60000)]
+    ocol, ohits, osh, _ = oracle.trace_batch(sub, depth=3)
+    gcol, ghits, gsh, _ = r.trace_batch(sub, depth=3)
     r.close()
+    agree = (ghits["prim"] == ohits["prim"]) & (ohits["hit"] == 1)
+    sh_same = (gsh[agree] == osh[agree]).all(axis=1)
+    valid = ~np.isnan(ocol).any(axis=1)
+    dcol = np.abs(gcol - ocol)[valid].max(axis=1)
+    print(f"{name}: {len(sub)} of them as trace_ray at depth 3: shadow flags differ on {int((~sh_same).sum())} of {int(agree.sum())} hits, "
+          f"colour max |d| {dcol.max():.2e}, beyond 1e-5: {int((dcol > 1e-5).sum())}")
+    # (a flag may differ where it cannot matter: shadow rays whose pending radiance is exactly zero are not traced)
+    assert (~sh_same).sum() <= max(1, len(sub) // 5000)
+    bad_flags = np.nonzero(agree)[0][~sh_same]
+    assert np.all(np.abs(gcol[bad_flags] - ocol[bad_flags]).max(axis=1) <= 1e-6) if len(bad_flags) else True
+    assert (dcol > 1e-5).sum() <= max(1, len(sub) // 10000)
     ghit = hits["hit"] == 1
     first = np.zeros(max(scene.n_objects, 1), np.int64)
     for obj, k in scene.mesh_first_triangle().items():
