@@ -76,7 +76,6 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     q.hits = (float2 *)take((c.ray_cap + 1) * sizeof(float2));
     q.shA = (float4 *)take(c.sh_cap * sizeof(float4));
     q.shC = (float4 *)take(c.sh_cap * sizeof(float4));
-    q.shL = (uint8_t *)take(c.sh_cap);
     q.accum = (long long *)take((size_t)c.ring * c.samples * 3 * sizeof(long long));
     q.general = (uint32_t *)take(c.general_cap * sizeof(uint32_t));
     q.general_cap = (uint32_t)c.general_cap;

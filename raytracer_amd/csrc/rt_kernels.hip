@@ -733,7 +733,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             uint32_t *join = reinterpret_cast<uint32_t *>(q.shC + ri) + 3;
             if (occl) atomicOr(join, RT_JOIN_OCCLUDED);
             const uint32_t old = atomicSub(join, 1u);
-            add = !occl && old == 1u;  // (old carries the flag if any earlier item set it)
+            add = !occl && (old & ~RT_JOIN_LIGHT_MASK) == 1u;  // (old carries the flag if any earlier item set it)
             occl = false;
         }
         if (COUNT && ANY && add) unocc++;
@@ -859,13 +859,13 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
                 if (!nothing) A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
                 if (!ANY && prim_here && ray_i < q.prim_n) A = q.primA;  // (wave-uniform prim_here: only where primary rays walk per lane)
-                if (ANY && !nothing) light = q.shL[ray_i];
+                if (ANY && !nothing) light = rtJoinLight(__float_as_uint(q.shC[ray_i].w));  // (the record's light rides in its join word)
                 if (!ANY) B = q.rayB[buf][ray_i];
                 if (ANY && !SPLIT) nothing = __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
             }
             uint32_t old_light = 0;
             if (ANY && fin) C = q.shC[old_i];
-            if (ANY && fin && l0store) old_light = q.shL[old_i];
+            if (ANY && fin && l0store) old_light = rtJoinLight(__float_as_uint(C.w));
             if (fin) writeResult(old_i, old_sample, C, old_light);
             if (take && !nothing) {
                 float ldist = 0.0f;
@@ -984,7 +984,10 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             ++iter;
         } while ((int)__popcll(__ballot(has)) >= leave_below && (iter & period) != 0);
     }
-    if (fin) writeResult(ray_i, sample, ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0), l0store ? (uint32_t)q.shL[ray_i] : 0u);
+    if (fin) {
+        const float4 Cl = ANY ? q.shC[ray_i] : make_float4(0, 0, 0, 0);
+        writeResult(ray_i, sample, Cl, l0store ? rtJoinLight(__float_as_uint(Cl.w)) : 0u);
+    }
     if (COUNT) {
         if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
         flushStats(q.counters, st, ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES);
@@ -1559,11 +1562,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 endv = end;
             }
             if (lit) {
-                if (slot < q.shadow_cap) {  // 33-byte record: point + sample, light, pending colour (rtShadowRay rebuilds the ray)
+                if (slot < q.shadow_cap) {  // 32-byte record: point + sample, pending colour + light (rtShadowRay rebuilds the ray)
                     q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | (level == 0 ? RT_SHADOW_L0 : 0u)));
                     if (level == 0) l0lit++;
-                    q.shL[slot] = (uint8_t)l;
-                    q.shC[slot] = make_float4(c3.x, c3.y, c3.z, 0.0f);
+                    q.shC[slot] = make_float4(c3.x, c3.y, c3.z, __uint_as_float((uint32_t)l << RT_JOIN_LIGHT_SHIFT));
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                 }
@@ -1607,7 +1609,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                     q.rayA[nbuf][slot] = make_float4(ro.x, ro.y, ro.z, wRefl);
                     q.rayB[nbuf][slot] = make_float4(reflDir.x, reflDir.y, reflDir.z,
                                                      __uint_as_float(ntag | (emitRefr ? RT_FLAG_HAS_REFR_SIBLING : 0u)));
-                    q.rayR[nbuf][slot] = fresnelR;
+                    if (emitRefr) q.rayR[nbuf][slot] = fresnelR;  // (only read for a reflection ray with a refraction sibling)
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                 }
@@ -1618,7 +1620,6 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                     const V3 ro = P + RT_EPSILON * refrDir;  // main.cpp:181
                     q.rayA[nbuf][slot] = make_float4(ro.x, ro.y, ro.z, wRefr);
                     q.rayB[nbuf][slot] = make_float4(refrDir.x, refrDir.y, refrDir.z, __uint_as_float(ntag));
-                    q.rayR[nbuf][slot] = 1.0f;
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                 }

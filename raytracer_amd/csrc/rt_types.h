@@ -187,7 +187,6 @@ struct RtQueues {
     float *rayR[2];
     float2 *hits;
     float4 *shA, *shC;
-    uint8_t *shL;              // light index of a shadow record (one byte per slot)
     long long *accum;          // [ring samples][3] fixed point
     uint32_t *counters;        // see RtCounter
     uint32_t *spill;           // traversal stack entries beyond the LDS part: [entry][grid thread]
@@ -276,3 +275,7 @@ struct RtQueues {
 #define RT_CNT_WORDS (RT_CNT_SPLIT_BASE + RT_CNT_STRIDE)  // (2 parities x 7 rounds x 2 words fit one stride)
 #define RT_SPLIT_NULL 0xFFFFFFFFu     // ray index of an item that holds no work (reserved slots of a wave that could not export)
 #define RT_JOIN_OCCLUDED 0x80000000u  // join word of a split shadow ray (shC.w as u32): outstanding items | this flag
+// The same word carries the record's light index (<= 16 lights) in bits 24..27: k_shade writes it with the colour, the walks
+// read it at refill -- no byte array of its own (it was one more scattered store per shadow ray in k_shade).
+#define RT_JOIN_LIGHT_SHIFT 24
+#define RT_JOIN_LIGHT_MASK 0x0F000000u
