@@ -422,8 +422,6 @@ RT_DEV float rtToneMap1(float x) {
     return gclamp(gmin(n, 1.0f), 0.0f, 1.0f);
 }
 
-RT_DEV uint32_t rtJoinLight(uint32_t join_word) { return (join_word & RT_JOIN_LIGHT_MASK) >> RT_JOIN_LIGHT_SHIFT; }
-
 // fixed-point accumulator conversion (DESIGN.md "deterministic accumulation")
 RT_DEV long long rtToFixed(float x) {
     if (!(x == x)) return 0;  // NaN contributions are dropped (the reference would poison the pixel)

@@ -76,6 +76,8 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     q.hits = (float2 *)take((c.ray_cap + 1) * sizeof(float2));
     q.shA = (float4 *)take(c.sh_cap * sizeof(float4));
     q.shC = (float4 *)take(c.sh_cap * sizeof(float4));
+    q.shSlabLight = (uint8_t *)take(c.sh_cap / 64 + 1);  // (slabs hold at least 64 slots)
+    q.sh_slab_shift = 6;                                 // (rtSetSlab: the frame's slab size)
     q.accum = (long long *)take((size_t)c.ring * c.samples * 3 * sizeof(long long));
     q.general = (uint32_t *)take(c.general_cap * sizeof(uint32_t));
     q.general_cap = (uint32_t)c.general_cap;
@@ -94,6 +96,13 @@ size_t carveQueues(unsigned char *base, const CarveSpec &c, uint32_t *spill, RtQ
     q.sample_mask = (1u << q.level_shift) - 1u;
     q.tile_stride = 1;  // (set per frame: enqueueFrame)
     return off;
+}
+
+// slots per slab of the shadow queue (a power of two >= 64: rtShadeSlab) as every kernel of the frame sees it
+void rtSetSlab(RtQueues &q, uint32_t slab) {
+    uint32_t sh = 0;
+    while ((1u << sh) < slab) sh++;
+    q.sh_slab_shift = sh;
 }
 
 // A frame's primary rays: (origin, weight) is what k_gen_primary would store for every one of them (RtQueues::primA)
@@ -537,6 +546,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         for (int l = 0; l < pl.lanes; l++) {  // (every lane its own queues, counters and traversal spill area)
             carveQueues(ctx->d_arena.p + (size_t)l * (pl.bytes / (size_t)pl.lanes), pl.spec, ctx->d_spill.p + (size_t)l * ctx->spill_words, q[l]);
             rtImplyPrimaryOrigin(q[l], f);
+            rtSetSlab(q[l], pl.z.slab);
         }
         cfg.shade_slab = pl.z.slab;
         if (getenv("RT_VERBOSE"))
@@ -705,6 +715,7 @@ int renderTilesStatic(rt_context *ctx, const rt_camera *cam, const rt_render_par
     RtQueues q;
     carveQueues((unsigned char *)ctx->scratch, pl.spec, ctx->d_spill.p, q);
     rtImplyPrimaryOrigin(q, f);
+    rtSetSlab(q, pl.z.slab);
     KernelTimer kt;  // (off)
     if (enqueueFrame(ctx, cfg, f, pl, &q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, true, kt, nullptr)) return 1;
     HIPOK(hipGetLastError());
@@ -743,6 +754,7 @@ int traceBatch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, flo
     RtQueues q0;
     carveQueues(ctx->d_arena.p, pl.spec, ctx->d_spill.p, q0);
     cfg.shade_slab = pl.z.slab;
+    rtSetSlab(q0, pl.z.slab);
     DevBuf<float> d_rays, d_col;
     DevBuf<rt_hit> d_hits;
     DevBuf<uint8_t> d_sh;

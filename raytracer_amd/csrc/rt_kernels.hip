@@ -733,7 +733,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             uint32_t *join = reinterpret_cast<uint32_t *>(q.shC + ri) + 3;
             if (occl) atomicOr(join, RT_JOIN_OCCLUDED);
             const uint32_t old = atomicSub(join, 1u);
-            add = !occl && (old & ~RT_JOIN_LIGHT_MASK) == 1u;  // (old carries the flag if any earlier item set it)
+            add = !occl && old == 1u;  // (old carries the flag if any earlier item set it)
             occl = false;
         }
         if (COUNT && ANY && add) unocc++;
@@ -859,13 +859,13 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
                 }
                 if (!nothing) A = ANY ? q.shA[ray_i] : q.rayA[buf][ray_i];
                 if (!ANY && prim_here && ray_i < q.prim_n) A = q.primA;  // (wave-uniform prim_here: only where primary rays walk per lane)
-                if (ANY && !nothing) light = rtJoinLight(__float_as_uint(q.shC[ray_i].w));  // (the record's light rides in its join word)
+                if (ANY && !nothing) light = q.shSlabLight[ray_i >> q.sh_slab_shift];  // (a slab holds rays towards ONE light)
                 if (!ANY) B = q.rayB[buf][ray_i];
                 if (ANY && !SPLIT) nothing = __float_as_uint(A.w) == RT_SHADOW_HOLE;  // unused slot of a k_shade slab
             }
             uint32_t old_light = 0;
             if (ANY && fin && !occl) C = q.shC[old_i];  // (an occluded ray adds nothing: 60 % of the competition frame's shadow rays)
-            if (ANY && fin && l0store) old_light = rtJoinLight(__float_as_uint(C.w));
+            if (ANY && fin && l0store) old_light = q.shSlabLight[old_i >> q.sh_slab_shift];
             if (fin) writeResult(old_i, old_sample, C, old_light);
             if (take && !nothing) {
                 float ldist = 0.0f;
@@ -986,7 +986,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     }
     if (fin) {
         const float4 Cl = (ANY && !occl) ? q.shC[ray_i] : make_float4(0, 0, 0, 0);
-        writeResult(ray_i, sample, Cl, l0store ? rtJoinLight(__float_as_uint(Cl.w)) : 0u);
+        writeResult(ray_i, sample, Cl, l0store ? (uint32_t)q.shSlabLight[ray_i >> q.sh_slab_shift] : 0u);
     }
     if (COUNT) {
         if (walk) atomicMax(q.counters + (ANY ? RT_CNT_ANY_NODES : RT_CNT_NODES) + 4, walk);
@@ -1551,6 +1551,9 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
             if (c > room) {  // the slab is used up to its last slot, the rest of the rays opens the next one
                 const uint32_t sz = slabS;
                 const uint32_t nbase = waveReserve(q.counters + RT_CNT_SHADOW(par), sz);
+                // (every reservation on this counter is one slab: slabs are aligned, and slot >> log2(slab) names the slab --
+                // its light is written once here instead of a byte per ray)
+                if (lane == 0 && nbase < q.shadow_cap) q.shSlabLight[nbase >> q.sh_slab_shift] = (uint8_t)l;
                 if (rank >= room) slot = nbase + (rank - room);
                 cur = nbase + (c - room);
                 end = nbase + sz;
@@ -1562,10 +1565,10 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_BLOCKS_PER_CU) void k_shade(RtSc
                 endv = end;
             }
             if (lit) {
-                if (slot < q.shadow_cap) {  // 32-byte record: point + sample, pending colour + light (rtShadowRay rebuilds the ray)
+                if (slot < q.shadow_cap) {  // 32-byte record: point + sample, pending colour (rtShadowRay rebuilds the ray; the light: shSlabLight)
                     q.shA[slot] = make_float4(P.x, P.y, P.z, __uint_as_float(sample | (level == 0 ? RT_SHADOW_L0 : 0u)));
                     if (level == 0) l0lit++;
-                    q.shC[slot] = make_float4(c3.x, c3.y, c3.z, __uint_as_float((uint32_t)l << RT_JOIN_LIGHT_SHIFT));
+                    q.shC[slot] = make_float4(c3.x, c3.y, c3.z, 0.0f);
                 } else {
                     atomicAdd(q.counters + RT_CNT_OVERFLOW, 1u);
                 }

@@ -193,6 +193,11 @@ struct RtQueues {
     uint32_t *general;         // queue indices of the hits the fast k_shade leaves to the general one
     uint2 *split[2];           // work items (shadow ray, subtree) of any-hit walks split for being long; ping-pong by round
     uint32_t ray_cap, shadow_cap, split_cap, general_cap;
+    // k_shade reserves the shadow queue a slab (2^sh_slab_shift slots) at a time and fills a slab with rays towards ONE light:
+    // the light of record k is shSlabLight[k >> sh_slab_shift], written once per slab (a byte per record was one more
+    // scattered store per shadow ray in k_shade and 2.8 GB each way per 4K frame)
+    uint8_t *shSlabLight;
+    uint32_t sh_slab_shift;
     // RT_TAILPROF (diagnosis): per launch and wave {start, left phase 0, left phase 1, end} in 100 MHz ticks, at
     // tailprof[(launch_id * RT_TAIL_WAVES + wave) * 4]; null = off
     unsigned long long *tailprof;
@@ -275,7 +280,3 @@ struct RtQueues {
 #define RT_CNT_WORDS (RT_CNT_SPLIT_BASE + RT_CNT_STRIDE)  // (2 parities x 7 rounds x 2 words fit one stride)
 #define RT_SPLIT_NULL 0xFFFFFFFFu     // ray index of an item that holds no work (reserved slots of a wave that could not export)
 #define RT_JOIN_OCCLUDED 0x80000000u  // join word of a split shadow ray (shC.w as u32): outstanding items | this flag
-// The same word carries the record's light index (<= 16 lights) in bits 24..27: k_shade writes it with the colour, the walks
-// read it at refill -- no byte array of its own (it was one more scattered store per shadow ray in k_shade).
-#define RT_JOIN_LIGHT_SHIFT 24
-#define RT_JOIN_LIGHT_MASK 0x0F000000u
