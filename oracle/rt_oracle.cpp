@@ -981,8 +981,8 @@ static void orderRef(const Mesh &m, int node, uint32_t &next, uint32_t *rank) {
 // rt_get_bvh hands it over (64-byte 4-wide nodes with 8-bit child boxes, rt_types.h: RtNode4; leaf reference =
 // 0x80000000 | (count - 1) << 28 | (n_nodes + first slot); tri_order[slot] = global triangle) is walked for one ray at a
 // time with the traversal kernel's own arithmetic and order (raytracer_amd/csrc/rt_kernels.hip: rtInitWalk, rtNodeStep,
-// rtTriStep, rtPostponeLeaf and the phase rule of traceQueue for a wave whose lanes all hold the same ray: a node step
-// whenever the lane stands at a node, else a triangle step), counting node steps and triangle tests.  No analytic
+// rtTriStep, rtPostponeLeaf and the phase rule of traceQueue for a wave whose lanes all hold the same ray: a triangle step
+// whenever a leaf is pending -- node phase iff nNode >= 2 nTri, RT_VOTE_NODE 1/2 -- else a node step), counting node steps and triangle tests.  No analytic
 // primitives (the test scene has none).  out_slot = BVH slot of the closest triangle or -1.
 int ro_walk_counts(const ro_scene *rs, uint32_t root_ref, float bound, int64_t n_nodes, const uint32_t *nodes, const uint32_t *tri_order,
                    const int32_t *tri_object, const uint32_t *rank, int64_t n_rays, const float *rays, uint64_t *out_nodes,
@@ -1020,7 +1020,8 @@ int ro_walk_counts(const ro_scene *rs, uint32_t root_ref, float bound, int64_t n
                 pend = cur;
                 if (stack.empty()) cur = DONE; else { cur = stack.back(); stack.pop_back(); }
             }
-            if (!(cur & LEAF)) {  // node step
+            // (the wave's vote with every lane on the same ray: RT_VOTE_NODE 1/2 -- a pending leaf goes first)
+            if (pend == DONE && !(cur & LEAF)) {  // node step
                 nn++;
                 const uint32_t *q = nodes + 16 * (size_t)(cur & MASK);
                 const float org[3] = {asF(q[0]), asF(q[1]), asF(q[2])};

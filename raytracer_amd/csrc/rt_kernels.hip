@@ -521,8 +521,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_gen_primary(RtFrameDev f, RtQueues
 // work counter is ONE address, and at 256 shadow rays per atomic its returning atomics saturate (k_any 332 ms; 512:
 // 298 ms; 1024: 300 ms); closest-hit queues hold fewer, longer walks and prefer the better balance of 256 (234 ms;
 // 1024: 247 ms).  Refill threshold: 16 lanes is 4 ms better than 24 or 32.
+// Swept again at the end of round 3 (fused launch, 8 cursors per queue, sorted batches, pre-split tree; frame 387.2 ms):
+// shadow batches of 256 / 1024 / 2048 / 4096: +8.9 / -2.4 / -3.3 / -2.3 ms; closest 512 (unsorted): +11; refill 12 / 24: +2.
 #ifndef RT_FETCH_BATCH_ANY
-#define RT_FETCH_BATCH_ANY 512u
+#define RT_FETCH_BATCH_ANY 2048u
 #endif
 #ifndef RT_FETCH_BATCH_CLOSEST
 #define RT_FETCH_BATCH_CLOSEST 256u
@@ -924,9 +926,12 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
             const bool atNode = has && !(w.cur & RT_NODE_LEAF), atTri = has && w.pend != RT_NODE_DONE;
             const int nNode = (int)__popcll(__ballot(atNode)), nTri = (int)__popcll(__ballot(atTri));
             const unsigned long long tPhase = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
-#ifndef RT_VOTE_NODE_NUM  // node phase iff nNode * NUM >= nTri * DEN (sweep variants; 1/1 = the larger group)
+#ifndef RT_VOTE_NODE_NUM  // node phase iff nNode * NUM >= nTri * DEN (1/1 = the larger group)
+// (closest-hit walks: a triangle step is what shortens the ray and lets the next node steps cull, and since the large triangles
+// are cut into pieces there are few of them per ray -- they go first unless twice as many lanes wait at a node: 1/1 387.2 ms per
+// 4K frame, 3/4 384.9, 2/3 385.2, 1/2 383.9, 2/5 and 1/3 the same)
 #define RT_VOTE_NODE_NUM 1
-#define RT_VOTE_NODE_DEN 1
+#define RT_VOTE_NODE_DEN 2
 #endif
 #ifndef RT_VOTE_ANY_NUM  // any-hit: a new ray's first triangle step is its cached occluder, so triangle phases get a head start
 #define RT_VOTE_ANY_NUM 2   // (k_any on the 4K frame: 1/1 260 ms, 2/3 255, 1/2 257, 1/3 260, 1/4 266)

@@ -5,7 +5,7 @@ same rays.
 How many nodes a ray visits in the per-lane kernel depends on which phase its wave votes for (a node step taken before a
 pending leaf's triangles sees the older, larger best distance), so the identity is stated where it is a function of the ray
 alone: every ray is traced 256 times in a row -- a closest-hit batch, whichever order it is consumed in, then holds ONE ray, all
-lanes of a wave walk in lock step, and the vote is "node step whenever the ray stands at a node" -- with the packet kernel off
+lanes of a wave walk in lock step, and the vote is "triangle step whenever a leaf is pending" (node phase iff nNode >= 2 nTri) -- with the packet kernel off
 (RT_PACKET_LEVELS=0: primary rays walk per lane like every other ray).  Scene: the competition meshes alone (no analytic
 primitives: their hits would set the initial best distance)."""
 import copy
