@@ -160,14 +160,15 @@ struct RtFrameDev {
 #define RT_SHADOW_HOLE 0xFFFFFFFFu            // w of a shadow record that holds no ray (unused slot of a k_shade slab)
 #define RT_SHADOW_L0 0x40000000u              // w of a shadow record: the ray left a level-0 hit (RtQueues::occ0)
 #ifndef RT_SLAB_MAX
-#define RT_SLAB_MAX 1024u                    // slots a k_shade wave reserves at a time, per light / for the next level
-#endif
+#define RT_SLAB_MAX 2048u                    // slots a k_shade wave reserves at a time, per light / for the next level
+#endif                                       // (4K frame, end of round 3: 512: +9.5 ms, 1024: 0, 2048: -2.2, 4096: +5 -- k_shade pays for the holes)
 #ifndef RT_SHADE_BLOCKS_PER_CU
 #define RT_SHADE_BLOCKS_PER_CU 4
 #endif
 #ifndef RT_SHADE_SEGMENT
-#define RT_SHADE_SEGMENT 1024u                // consecutive queue entries a k_shade wave shades before it jumps
-#endif
+#define RT_SHADE_SEGMENT 2048u                // consecutive queue entries a k_shade wave shades before it jumps
+#endif                                        // (512: +9 ms, 1024: 0, 2048: -2.5; 2048 with slabs of 2048: -5.4, 4096 / 2048: the same; longer
+                                              // runs of neighbouring hits in the queues are what the traversal launch gains from)
 #define RT_TRACE_LDS_ROWS 2                  // LDS rows of 256 words behind a traversal block's stack rows: ages / batch order, sort bins
 #define RT_TAIL_WAVES 8192                   // waves of a launch that RT_TAILPROF records
 #define RT_BLOCK 256                         // threads per block of every kernel
