@@ -664,7 +664,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     const RtAnalytic &an = tl.an;
     const int buf = par;
     constexpr bool SPLIT = MODE == RT_MODE_SPLIT;
-    constexpr uint32_t batch = ANY ? RT_FETCH_BATCH_ANY : RT_FETCH_BATCH_CLOSEST;
+    constexpr uint32_t batch_max = ANY ? RT_FETCH_BATCH_ANY : RT_FETCH_BATCH_CLOSEST;
     static_assert(ANY || !SPLIT, "only any-hit walks are split");
     const uint32_t n = SPLIT ? min(q.counters[RT_CNT_SPLIT(par, round)], q.split_cap)
                              : (ANY ? min(q.counters[RT_CNT_SHADOW(par)], q.shadow_cap) : min(q.counters[RT_CNT_RAYS(par)], q.ray_cap));
@@ -675,6 +675,11 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     constexpr uint32_t PARTS = MODE == RT_MODE_QUEUE ? RT_WORK_PARTS : 1u;
     uint32_t *work_parts = q.counters + (ANY ? RT_CNT_WORKP_ANY(par, 0) : RT_CNT_WORKP_CLOSEST(par, 0));
     const uint32_t span = n > first ? n - first : 0u;     // entries [first, n) are this launch's
+    // (shadow queues of small chunks -- a small workspace, one GPU's share of a frame -- take smaller batches, down to 512: a
+    // wave should get ~4 of them, or the last ones keep a few waves busy while the chip idles)
+    uint32_t batch = batch_max;
+    if (ANY && MODE == RT_MODE_QUEUE)
+        while (batch > 512u && batch * (gridDim.x * (RT_BLOCK / 64) * 4u) > span) batch >>= 1;
     const bool prim_here = !ANY && q.prim_implied && first < q.prim_n;  // primary rays in this queue walk: their origin is RtQueues::primA
     const uint32_t part_len = PARTS > 1 ? ((span + PARTS - 1) / PARTS + batch - 1) / batch * batch : span;
     uint32_t part = PARTS > 1 ? blockIdx.x % PARTS : 0u, parts_done = 0;  // wave-uniform
@@ -688,7 +693,7 @@ RT_DEV void traceQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues &
     bool occl = false;                                     // SPLIT: the finished item found a hit
     RtTraversalStats st{0, 0};
     uint32_t pool_next = 0, pool_end = 0, pool_base = 0;  // wave-uniform
-    constexpr bool SORTED = RT_SORT_BATCH && !ANY && MODE == RT_MODE_QUEUE && batch <= 256u;  // rtSortBatch
+    constexpr bool SORTED = RT_SORT_BATCH && !ANY && MODE == RT_MODE_QUEUE && batch_max <= 256u;  // rtSortBatch
     bool sorted = false;                                   // wave-uniform: the current batch has an order in LDS
     uint32_t part_seen = 0;                                // how far the current part had got at this wave's last fetch
 #ifndef RT_TAIL_FACTOR
