@@ -507,6 +507,9 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
     d.nodes = ctx->d_records.p;
     d.tri_geom = reinterpret_cast<const RtTriGeom *>(ctx->d_records.p + nn);
     d.bound = src->bvh.bound;
+    d.reach = src->bvh.bound;  // (+ the unit primitives' boxes: how far the finite geometry reaches, rtUnitCull)
+    for (const RtSphere &u : img.units)
+        for (int a = 0; a < 3; a++) d.reach = std::fmax(d.reach, std::fmax(std::fabs(u.box_mn[a]), std::fabs(u.box_mx[a])));
     d.nodes_p = ctx->d_nodes_p.p;
     d.tri_shade = ctx->d_shade.p;
     d.spheres = ctx->d_spheres.p;

@@ -106,9 +106,10 @@ void rtSetSlab(RtQueues &q, uint32_t slab) {
 }
 
 // A frame's primary rays: (origin, weight) is what k_gen_primary would store for every one of them (RtQueues::primA)
-void rtImplyPrimaryOrigin(RtQueues &q, const RtFrameDev &f) {
+void rtImplyPrimaryOrigin(RtQueues &q, const RtFrameDev &f, float reach) {
     q.primA = make_float4(f.origin[0], f.origin[1], f.origin[2], 1.0f);
     q.prim_implied = 1u;
+    q.prim_far = std::fmax(std::fmax(std::fabs(f.origin[0]), std::fabs(f.origin[1])), std::fabs(f.origin[2])) > 4.0f * reach ? 1u : 0u;
 }
 
 // How a frame of `n_local` tiles is cut into chunks and what its queues hold.
@@ -545,7 +546,7 @@ int renderTiles(rt_context *ctx, const rt_camera *cam, const rt_render_params *p
         RtQueues q[2];
         for (int l = 0; l < pl.lanes; l++) {  // (every lane its own queues, counters and traversal spill area)
             carveQueues(ctx->d_arena.p + (size_t)l * (pl.bytes / (size_t)pl.lanes), pl.spec, ctx->d_spill.p + (size_t)l * ctx->spill_words, q[l]);
-            rtImplyPrimaryOrigin(q[l], f);
+            rtImplyPrimaryOrigin(q[l], f, ctx->dev.reach);
             rtSetSlab(q[l], pl.z.slab);
         }
         cfg.shade_slab = pl.z.slab;
@@ -714,7 +715,7 @@ int renderTilesStatic(rt_context *ctx, const rt_camera *cam, const rt_render_par
                     " MiB static scratch (lower spp or max_depth, or use rt_render_tiles_device)");
     RtQueues q;
     carveQueues((unsigned char *)ctx->scratch, pl.spec, ctx->d_spill.p, q);
-    rtImplyPrimaryOrigin(q, f);
+    rtImplyPrimaryOrigin(q, f, ctx->dev.reach);
     rtSetSlab(q, pl.z.slab);
     KernelTimer kt;  // (off)
     if (enqueueFrame(ctx, cfg, f, pl, &q, p->max_depth, (size_t)n_local, in.per_tile, d_rgb8, d_rgbf, d_primid, 0, true, kt, nullptr)) return 1;
@@ -755,6 +756,7 @@ int traceBatch(rt_context *ctx, int64_t n, const float *rays, int32_t depth, flo
     carveQueues(ctx->d_arena.p, pl.spec, ctx->d_spill.p, q0);
     cfg.shade_slab = pl.z.slab;
     rtSetSlab(q0, pl.z.slab);
+    q0.prim_far = 1u;  // (rays of unknown origin: always the reference's arithmetic)
     DevBuf<float> d_rays, d_col;
     DevBuf<rt_hit> d_hits;
     DevBuf<uint8_t> d_sh;

@@ -351,6 +351,13 @@ RT_DEV RtAnalytic stageAnalytic(const RtSceneDev &sc, uint32_t *lds_after_stack)
     __syncthreads();
     return RtAnalytic{reinterpret_cast<const RtSphere *>(dst), reinterpret_cast<const RtPlane *>(dst + nsw)};
 }
+// The box pre-test of the unit primitives is only sound where the reference's own test is accurate.  That test works in the
+// primitive's object space, in floats: `cdotc - cdotd * cdotd` (Objects.h:44-49) cancels once the origin is many radii away, and
+// from thousands of radii it accepts every other ray (seen from 1 300 scene sizes the reference draws a 0.03 sphere as a blob a
+// third of the frame wide: scripts/gpu_r3_far_camera.py).  A frame whose CAMERA stands farther out than four times the scene's
+// reach therefore traces its primary rays without the pre-test (RtQueues::prim_far, a launch argument: the packet phase) and
+// gets the reference's arithmetic, whatever it says.  (Deciding per ray in the per-lane walks -- a bounce off the horizon of
+// an infinite plane starts as far out -- cost the 4K frame 6 to 11 ms in registers and code: not done)
 // padded world box of a sphere: a ray that misses it cannot hit the sphere (plain slab test, no quantisation)
 RT_DEV bool sphereBoxHit(const RtSphere &sp, V3 inv, V3 oi) {
     const float ax = __builtin_fmaf(sp.box_mn[0], inv.x, -oi.x), bx = __builtin_fmaf(sp.box_mx[0], inv.x, -oi.x);
@@ -376,14 +383,15 @@ RT_DEV float rtFarLimit(const RtSceneDev &sc, const RtWalk &w) {
 // triangle, so which of these a ray "hit" depended on the tree, on the walk (packet boxes are exact, per-lane boxes 8-bit)
 // and on the 63 rays sharing its packet.  With the limit a ray's result is a function of the ray and the scene alone
 // (what that costs in agreement with the reference -- its own such hits, ~1 per 10^8 rays -- and buys).
-RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &w) {
+template <bool CULL>
+RT_DEV void analyticClosestT(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &w) {
     w.best_t = INFINITY;
     w.best_id = RT_ID_MISS;
     w.best_obj = 0x7FFFFFFF;
     w.best_rank = 0;
     for (int k = 0; k < sc.n_spheres; k++) {
         const RtSphere &sp = an.spheres[k];
-        if (!sphereBoxHit(sp, w.inv, w.oi)) continue;
+        if (CULL && !sphereBoxHit(sp, w.inv, w.oi)) continue;
         float dist;
         V3 ni, P;
         if (rtUnitPrimHit(sp, w.r, dist, ni, P) && (dist < w.best_t || (dist == w.best_t && w.best_id != RT_ID_MISS && sp.object < w.best_obj))) {
@@ -403,20 +411,25 @@ RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &
     }
     if (w.best_id == RT_ID_MISS) w.best_t = rtFarLimit(sc, w);
 }
+RT_DEV void analyticClosest(const RtSceneDev &sc, const RtAnalytic &an, RtWalk &w) { analyticClosestT<true>(sc, an, w); }
 // is_shadowed() after its back-face test, analytic part: any primitive with hit.distance <= dist (main.cpp:50-55)
-RT_DEV bool analyticOccluded(const RtSceneDev &sc, const RtAnalytic &an, const RtWalk &w, float dist) {
+template <bool CULL>
+RT_DEV bool analyticOccludedT(const RtSceneDev &sc, const RtAnalytic &an, const RtWalk &w, float dist) {
     for (int k = 0; k < sc.n_planes; k++) {
         float t;
         if (rtPlaneHit(an.planes[k], w.r, t) && t <= dist) return true;
     }
     for (int k = 0; k < sc.n_spheres; k++) {
         const RtSphere &sp = an.spheres[k];
-        if (!sphereBoxHit(sp, w.inv, w.oi)) continue;
+        if (CULL && !sphereBoxHit(sp, w.inv, w.oi)) continue;
         float d;
         V3 ni, P;
         if (rtUnitPrimHit(sp, w.r, d, ni, P) && d <= dist) return true;
     }
     return false;
+}
+RT_DEV bool analyticOccluded(const RtSceneDev &sc, const RtAnalytic &an, const RtWalk &w, float dist) {
+    return analyticOccludedT<true>(sc, an, w, dist);
 }
 
 // whole-ray forms (test hook k_hitinfo)
@@ -1058,7 +1071,10 @@ RT_DEV void tracePacket(const RtSceneDev &sc, const RtTraceLds &tl, uint32_t roo
     w.best_obj = 0x7FFFFFFF;
     w.best_rank = 0;
     if (sample & RT_FLAG_INVALID) alive = false;  // slot of a pixel outside the image: recorded as a miss
-    if (alive) analyticClosest(sc, an, w);
+    if (alive) {
+        if (q.prim_far) analyticClosestT<false>(sc, an, w);  // (uniform)
+        else analyticClosestT<true>(sc, an, w);
+    }
     const unsigned long long am = __ballot(alive);
     bool toResid = false;
     // error bound of a plane distance folded into o/d: near planes move towards the origin, far planes away

@@ -125,7 +125,7 @@ struct RtSceneDev {
     int32_t occluder_cache;      // k_any starts a ray on the triangle that last occluded a ray of its wave (rt_commit)
     uint64_t plane_general;      // bit k: plane k's material needs the general k_shade
     int32_t has_general;         // the scene holds primitives that need the general k_shade
-    int32_t _pad0;
+    float reach;                 // max |coordinate| of any node box or unit-primitive box: how far the finite geometry reaches
 };
 
 // Camera + image constants of the tile loop, precomputed on the host exactly as main.cpp:561-563 does.
@@ -211,6 +211,7 @@ struct RtQueues {
     // k_gen_primary's store, the packets' load, k_shade's load).  0 for rays handed in by the host (rt_trace_batch).
     float4 primA;
     uint32_t prim_implied;
+    uint32_t prim_far;         // the primary rays start far outside the scene (or anywhere: a host's batch): no box pre-test of the unit primitives
     uint32_t tile_stride;      // local tiles of a chunk: tile0 + k * tile_stride (tile0 = the chunk's number, stride = chunks of the frame)
     uint32_t l0_sample0;       // ring sample of the first level-0 shadow ray's chunk (the fused k_trace walks the shadow rays of
                                // iteration j next to the primary rays of chunk j + 1, which prim_n / prim_sample0 then describe)
