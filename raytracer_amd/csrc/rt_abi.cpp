@@ -546,7 +546,7 @@ int commitDevice(rt_context *ctx, const rt_context *src, const CommitImage &img)
         while (b > 1) { b >>= 1; p2++; }
         ctx->cfg.split_budget = atoi(e) > 0 ? 1 << p2 : 0;
     }
-    ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(8, (160 * 1024) / lds_per_block));
+    ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(RT_TRACE_MIN_BLOCKS, (160 * 1024) / lds_per_block));
     if (const char *e = getenv("RT_TRACE_BLOCKS")) ctx->cfg.trace_blocks_per_cu = std::max(1, std::min(ctx->cfg.trace_blocks_per_cu, atoi(e)));  // (tuning knob)
     const size_t spill_entries = (size_t)std::max(0, src->bvh.max_stack - entries);
     ctx->spill_words = std::max<size_t>(1, spill_entries * (size_t)ctx->cfg.num_cus * 8 * 256);

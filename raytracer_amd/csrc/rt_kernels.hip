@@ -1229,7 +1229,7 @@ RT_DEV void packetQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues 
     }
 }
 
-// The traversal kernels.  All of them use the same LDS layout (RtTraceLds) and 64 VGPRs (8 waves per SIMD).
+// The traversal kernels.  All of them use the same LDS layout (RtTraceLds) and 72 VGPRs (RT_TRACE_MIN_BLOCKS = 7 waves per SIMD).
 // k_trace is the FUSED form the frame loop launches once per iteration: its waves work off, one phase after the other
 // and each wave at its own pace, (1) the shadow queue of iteration j, (2) the bounce rays of iteration j + 1 (appended by
 // k_shade(j), which ran before this launch), (3) the primary rays of the chunk that enters at j + 1, as packets.  The
@@ -1237,7 +1237,7 @@ RT_DEV void packetQueue(const RtSceneDev &sc, uint32_t root_ref, const RtQueues 
 // that tail three times per iteration (~0.3 ms each), here the tails of (1) and (2) are filled by the next phase.
 // par_any / par_closest < 0: the phase has no work (first and last iterations).
 template <int STATS, bool L0>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_trace(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par_any, int par_closest, uint32_t first,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRACE_MIN_BLOCKS) void k_trace(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par_any, int par_closest, uint32_t first,
                                                        int packets, int stack_entries, uint32_t budget) {
     extern __shared__ uint32_t s_lds[];
     const unsigned long long tp0 = rtTailBegin(q);
@@ -1260,19 +1260,19 @@ __global__ __launch_bounds__(RT_BLOCK, 8) void k_trace(RtSceneDev sc, uint32_t r
 }
 // the phases as launches of their own (per-kernel timing: collect_stats & 2, RT_FUSE=0; rt_trace_batch; the split rounds)
 template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries) {
+__global__ __launch_bounds__(RT_BLOCK, RT_TRACE_MIN_BLOCKS) void k_packet(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
     const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
     packetQueue<STATS>(sc, root_ref, q, tl, par);
 }
 template <int STATS>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, uint32_t first, int stack_entries) {
+__global__ __launch_bounds__(RT_BLOCK, RT_TRACE_MIN_BLOCKS) void k_closest(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, uint32_t first, int stack_entries) {
     extern __shared__ uint32_t s_lds[];
     const RtTraceLds tl = rtTraceSetup(sc, q, s_lds, stack_entries);
     traceQueue<false, STATS, RT_MODE_QUEUE>(sc, root_ref, q, tl, par, first, -1, 0u);
 }
 template <int STATS, int MODE, bool L0 = false>
-__global__ __launch_bounds__(RT_BLOCK, 8) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries, int round,
+__global__ __launch_bounds__(RT_BLOCK, RT_TRACE_MIN_BLOCKS) void k_any(RtSceneDev sc, uint32_t root_ref, RtQueues q, int par, int stack_entries, int round,
                                                      uint32_t budget) {
     if (MODE == RT_MODE_SPLIT && q.counters[RT_CNT_SPLIT(par, round)] == 0) return;  // the usual case: nothing was split
     extern __shared__ uint32_t s_lds[];

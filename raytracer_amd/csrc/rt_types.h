@@ -169,6 +169,9 @@ struct RtFrameDev {
 #define RT_SHADE_SEGMENT 2048u                // consecutive queue entries a k_shade wave shades before it jumps
 #endif                                        // (512: +9 ms, 1024: 0, 2048: -2.5; 2048 with slabs of 2048: -5.4, 4096 / 2048: the same; longer
                                               // runs of neighbouring hits in the queues are what the traversal launch gains from)
+#ifndef RT_TRACE_MIN_BLOCKS
+#define RT_TRACE_MIN_BLOCKS 7                // blocks per CU the traversal kernels are compiled and launched for: 7 = 72 VGPRs.  (8 = 64 VGPRs with
+#endif                                       // 25 spilled VGPRs and 122 spilled SGPRs in the fused kernel: 4K frame 375.9 ms; 7: 374.3; 6 = 80 VGPRs: 387.3)
 #define RT_TRACE_LDS_ROWS 2                  // LDS rows of 256 words behind a traversal block's stack rows: ages / batch order, sort bins
 #define RT_TAIL_WAVES 8192                   // waves of a launch that RT_TAILPROF records
 #define RT_BLOCK 256                         // threads per block of every kernel
